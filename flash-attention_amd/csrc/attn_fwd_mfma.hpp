@@ -1,0 +1,405 @@
+// FlashAttention-2 forward for gfx950 (MI355X, CDNA4): fp16 operands on
+// v_mfma_f32_32x32x16_f16, fp32 accumulation, wave64.
+//
+// Functional counterpart of the reference's kernel_mma_qreg family
+// (reference flash/kernel_mma_qreg.cuh:16-267, kernel_mma_qreg_f32x4load.cuh,
+// kernel_mma_qreg_async.cuh): one workgroup owns a tile of Q rows of one (batch, head), keeps Q in
+// registers, streams K/V tiles through LDS and keeps the running row max / row sum in registers.
+// Nothing of the reference's structure is kept beyond that:
+//
+//   * A workgroup is 8 waves x 32 query rows = 256 rows (Br), K/V tiles are 64 rows (Bc).
+//   * Scores are produced TRANSPOSED: S^T = K * Q^T, A operand = K rows from LDS (ds_read_b128),
+//     B operand = Q held in VGPRs.  In the 32x32 accumulator layout the query index is then the
+//     lane (lane & 31) and the key index runs over the 16 registers, so the row max / row sum of
+//     the online softmax are in-lane reductions plus ONE v_permlane32_swap between the two
+//     half-waves; no LDS round trip for S or P (the reference stores S to shared memory three
+//     times per tile, kernel_mma_qreg.cuh:166,185,200).
+//   * The output is accumulated TRANSPOSED as well: O^T = V^T * P^T.  P^T is exactly the S^T
+//     accumulator converted to fp16 (8 consecutive registers = one B fragment with a permuted key
+//     order), V^T fragments come from the row-major V tile with ds_read_b64_tr_b16 using the same
+//     permuted key order.  The softmax rescale factor is a per-lane scalar for every register of
+//     O^T.  O stays in registers for the whole K/V sweep and is divided by the row sum once
+//     (the reference read-modify-writes O in HBM for every K/V tile, kernel_mma_qreg.cuh:207-250).
+//   * K/V tiles are double-buffered in LDS.  Staging is one of: direct global->LDS
+//     (buffer_load_dwordx4 ... lds), or through registers for head dims that are not a multiple
+//     of 8 halves and for fp32 callers.  The LDS image is XOR-swizzled at 16-byte granularity so
+//     that both the K row reads and the V transposed reads are bank-conflict free.
+//   * Out-of-range rows/columns are handled by the buffer descriptor's range check (loads return 0,
+//     stores are dropped); only the key-side tail needs an explicit -inf mask.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flash_hip {
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x4_b __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+#define FLASH_LDS_CAST(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+constexpr int kWaves = 8;                   // waves per workgroup
+constexpr int kRowsPerWave = 32;            // query rows per wave (one 32x32 MFMA column block)
+constexpr int kBr = kWaves * kRowsPerWave;  // 256 query rows per workgroup
+constexpr int kBc = 64;                     // key/value rows per LDS tile
+constexpr int kThreads = kWaves * 64;
+constexpr uint32_t kOob = 0x40000000u;      // byte offset beyond any per-head buffer (< 1 GiB each)
+
+enum Staging : int { kStageElem = 0, kStageVec = 1, kStageDma = 2 };
+
+struct FwdParams {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* o;
+  int N;              // sequence length
+  int d;              // head dim (<= D)
+  int nqt;            // query tiles per head = ceil(N / kBr)
+  uint32_t total_wg;  // B * H * nqt
+  float scale_log2e;  // softmax_scale * log2(e)
+};
+
+template <int D>
+struct Geom {
+  static_assert(D == 64 || D == 128, "compiled head-dim tiles are 64 and 128");
+  static constexpr int kRowBytes = D * 2;             // LDS row of fp16
+  static constexpr int kChunks = D / 8;               // 16-byte chunks per row
+  static constexpr int kKSteps = D / 16;              // MFMA k-steps of S^T = K Q^T
+  static constexpr int kDvBlocks = D / 32;            // 32-wide blocks of O^T rows
+  static constexpr int kTileBytes = kBc * kRowBytes;  // one K or V tile
+  static constexpr int kStageBytes = 2 * kTileBytes;  // K + V
+  static constexpr int kLdsBytes = 2 * kStageBytes;   // double buffered
+  static constexpr int kPieces = kTileBytes / 1024;   // 1-KiB wave-instructions per tile
+  static constexpr int kPiecesPerWave = kPieces / kWaves;
+};
+
+// 16-byte-chunk XOR swizzle of an LDS tile row.  Chosen so that
+//  - 16 lanes reading the same logical chunk of 16 rows that are distinct mod 16 (K operand,
+//    ds_read_b128) land on 16 different 16-byte slots of the 256-byte bank row, and
+//  - 32 lanes reading 64 bytes of each of 4 consecutive rows (V operand, ds_read_b64_tr_b16)
+//    cover the 256-byte bank row exactly once.
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if constexpr (D == 128) {
+    return ((row & 3) << 2) | ((row >> 2) & 3);
+  } else {
+    return (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+  }
+}
+
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * Geom<D>::kRowBytes + ((chunk ^ swz<D>(row)) << 4);
+}
+
+// x of this lane's row as held by the lower (r[0]) and the upper (r[1]) half-wave.
+struct HalfPair {
+  float lo, hi;
+};
+__device__ __forceinline__ HalfPair both_halves(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return {__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ f16 to_f16(f16 x) { return x; }
+__device__ __forceinline__ f16 to_f16(float x) { return (f16)x; }
+
+// ---- element access through a raw buffer descriptor (range-checked) --------------------------
+template <typename T>
+__device__ __forceinline__ f16 load_elem(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off);
+template <>
+__device__ __forceinline__ f16 load_elem<f16>(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+  unsigned short u = __builtin_amdgcn_raw_buffer_load_b16(rs, byte_off, 0, 0);
+  return __builtin_bit_cast(f16, u);
+}
+template <>
+__device__ __forceinline__ f16 load_elem<float>(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+  uint32_t u = __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0);
+  return (f16)__uint_as_float(u);
+}
+__device__ __forceinline__ void store_elem(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, f16 x) {
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, x), rs, byte_off, 0, 0);
+}
+__device__ __forceinline__ void store_elem(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, float x) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, byte_off, 0, 0);
+}
+
+// ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T ----------------------------------
+// kt / vt: LDS addresses of the swizzled K and V tiles.  qf: this wave's Q fragments.
+// o: O^T accumulators (row = dv, col = query = lane & 31).  m: running max of the raw scores,
+// l: this lane's partial row sum (its half-wave's share of the keys).
+template <int D, bool MASK>
+__device__ __forceinline__ void tile_compute(lds_char* kt, lds_char* vt,
+                                             const f16x8 (&qf)[Geom<D>::kKSteps],
+                                             f32x16 (&o)[Geom<D>::kDvBlocks], float& m, float& l,
+                                             float c, int kv0, int N, int lane) {
+  using G = Geom<D>;
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  // S^T blocks: keys kv0 + 32*blk + (reg&3) + 8*(reg>>2) + 4*h, query = r.
+  f32x16 s[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[blk][i] = 0.f;
+  }
+#pragma unroll
+  for (int ks = 0; ks < G::kKSteps; ++ks) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const f16x8 a = *(FLASH_LDS_CAST(f16x8, kt + lds_off<D>(blk * 32 + r, 2 * ks + h)));
+      s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[blk], 0, 0, 0);
+    }
+  }
+
+  if constexpr (MASK) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kv = kv0 + blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (kv >= N) s[blk][i] = -INFINITY;
+      }
+    }
+  }
+
+  // row max over this lane's 32 keys, then over both half-waves
+  float mx = s[0][0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+  const HalfPair mp = both_halves(mx);
+  const float m_new = fmaxf(m, fmaxf(mp.lo, mp.hi));
+
+  // rescale the running state to the new max (exp2 domain: c = scale * log2 e)
+  const float alpha = fast_exp2((m - m_new) * c);
+  m = m_new;
+  l *= alpha;
+#pragma unroll
+  for (int b = 0; b < G::kDvBlocks; ++b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
+  }
+
+  // P^T = exp2(S^T * c - m * c), packed to fp16 B fragments (k-step = 8 consecutive registers)
+  const float mc = m_new * c;
+  f16x8 pf[4];
+  float rs = 0.f;
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float pv = fast_exp2(__builtin_fmaf(s[blk][i], c, -mc));
+      rs += pv;
+      pf[blk * 2 + (i >> 3)][i & 7] = (f16)pv;
+    }
+  }
+  l += rs;
+
+  // O^T[dv][q] += sum_kv V[kv][dv] * P[q][kv].  A operand = V^T via transposed LDS reads; element j
+  // of half-wave h of k-step ks is key 16*ks + 8*(j>>2) + 4*h + (j&3), the order P^T's registers
+  // already have.
+  const int i16 = lane & 15;
+  const int tq = i16 >> 2;        // row of the 4x16 transposed block this lane addresses
+  const int tp = i16 & 3;         // 4-column group of that row
+  const int tg = (lane >> 4) & 1; // which 16 of the 32 dv columns
+#pragma unroll
+  for (int b = 0; b < G::kDvBlocks; ++b) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      f16x8 a;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int row = 16 * ks + 8 * jj + 4 * h + tq;
+        const int off = lds_off<D>(row, b * 4 + tg * 2 + (tp >> 1)) + 8 * (tp & 1);
+        const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(FLASH_LDS_CAST(fp16x4_b, vt + off));
+        const f16x4 tv = __builtin_bit_cast(f16x4, t);
+        a[4 * jj + 0] = tv[0];
+        a[4 * jj + 1] = tv[1];
+        a[4 * jj + 2] = tv[2];
+        a[4 * jj + 3] = tv[3];
+      }
+      o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[ks], o[b], 0, 0, 0);
+    }
+  }
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------
+// D: compiled head-dim tile (d <= D, missing columns are zero-filled).
+// T: element type of Q/K/V/O in HBM (f16 or float; float is rounded to f16 while staging).
+// FAST: T == f16 and d % 8 == 0: 128-bit Q loads, direct global->LDS K/V staging, 64-bit O stores.
+//       Otherwise everything goes through range-checked element loads/stores.
+template <int D, typename T, bool FAST>
+__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
+  using G = Geom<D>;
+  static_assert(!FAST || sizeof(T) == 2, "direct-to-LDS staging needs fp16 data in HBM");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_char* const smem = (lds_char*)smem_raw;
+
+  // Work item: consecutive items = query tiles of one head; items are dealt to the 8 XCDs in
+  // contiguous ranges (workgroup ids that are equal mod 8 share an XCD and hence an L2), so the
+  // workgroups that stream the same K/V run on the same L2 at about the same time.
+  const uint32_t bid = blockIdx.x;
+  const uint32_t xcd = bid & 7u, slot = bid >> 3;
+  const uint32_t per = p.total_wg >> 3, rem = p.total_wg & 7u;
+  const uint32_t item = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+  const uint32_t head = item / (uint32_t)p.nqt;
+  const uint32_t qt = item - head * (uint32_t)p.nqt;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+  const int N = p.N, d = p.d;
+
+  const size_t head_elems = (size_t)N * (size_t)d;
+  const uint32_t head_bytes = (uint32_t)(head_elems * sizeof(T));
+  const T* qh = (const T*)p.q + (size_t)head * head_elems;
+  const T* kh = (const T*)p.k + (size_t)head * head_elems;
+  const T* vh = (const T*)p.v + (size_t)head * head_elems;
+  T* oh = (T*)p.o + (size_t)head * head_elems;
+  const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qh, 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kh, 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vh, 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
+
+  const uint32_t row_bytes = (uint32_t)d * sizeof(T);
+  const uint32_t tile_step = (uint32_t)kBc * row_bytes;  // HBM bytes between consecutive K/V tiles
+
+  // ---- K/V staging --------------------------------------------------------------------------
+  // FAST: each wave issues kPiecesPerWave 1-KiB pieces per tensor; lane i of piece pc fills LDS
+  // chunk pc*64 + i, i.e. row (pc*64+i)/kChunks, slot (pc*64+i)%kChunks, with the source chunk that
+  // the swizzle maps there.
+  uint32_t dma_off[G::kPiecesPerWave];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < G::kPiecesPerWave; ++i) {
+      const int ci = (wave * G::kPiecesPerWave + i) * 64 + lane;
+      const int row = ci / G::kChunks;
+      const int src = (ci % G::kChunks) ^ swz<D>(row);
+      dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
+    }
+  }
+  auto stage = [&](int t, int buf) {
+    lds_char* const kdst = smem + buf * G::kStageBytes;
+    lds_char* const vdst = kdst + G::kTileBytes;
+    const uint32_t toff = (uint32_t)t * tile_step;
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < G::kPiecesPerWave; ++i) {
+        const int pc = wave * G::kPiecesPerWave + i;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, kdst + pc * 1024, 16, dma_off[i] + toff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, vdst + pc * 1024, 16, dma_off[i] + toff, 0, 0, 0);
+      }
+    } else {
+      // two adjacent columns per step, converted to fp16 and written as one dword
+      constexpr int kPairs = kBc * D / 2;
+#pragma unroll 4
+      for (int idx = tid; idx < kPairs; idx += kThreads) {
+        const int row = idx / (D / 2);
+        const int cp = idx % (D / 2);
+        const int col = 2 * cp;
+        const uint32_t base = toff + (uint32_t)row * row_bytes;
+        const uint32_t o0 = (col < d) ? base + (uint32_t)col * sizeof(T) : kOob;
+        const uint32_t o1 = (col + 1 < d) ? base + (uint32_t)(col + 1) * sizeof(T) : kOob;
+        f16x2 kk, vv;
+        kk[0] = load_elem<T>(k_rs, o0);
+        kk[1] = load_elem<T>(k_rs, o1);
+        vv[0] = load_elem<T>(v_rs, o0);
+        vv[1] = load_elem<T>(v_rs, o1);
+        const int off = lds_off<D>(row, cp >> 2) + (cp & 3) * 4;
+        *FLASH_LDS_CAST(f16x2, kdst + off) = kk;
+        *FLASH_LDS_CAST(f16x2, vdst + off) = vv;
+      }
+    }
+  };
+
+  const int nt = (N + kBc - 1) / kBc;
+  stage(0, 0);
+
+  // ---- Q fragments: B operand of S^T = K Q^T: lane (r, h) holds Q[row r][16*ks + 8*h + 0..7] ----
+  const int qrow = (int)qt * kBr + wave * kRowsPerWave + r;
+  f16x8 qf[G::kKSteps];
+#pragma unroll
+  for (int ks = 0; ks < G::kKSteps; ++ks) {
+    const int col = 16 * ks + 8 * h;
+    if constexpr (FAST) {
+      const uint32_t off = (col < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)col) * 2u : kOob;
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
+      qf[ks] = __builtin_bit_cast(f16x8, raw);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t off =
+            (col + j < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)(col + j)) * (uint32_t)sizeof(T) : kOob;
+        qf[ks][j] = load_elem<T>(q_rs, off);
+      }
+    }
+  }
+
+  f32x16 o[G::kDvBlocks];
+#pragma unroll
+  for (int b = 0; b < G::kDvBlocks; ++b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
+  }
+  float m = -3.0e38f;  // running max of raw scores (finite, so the first rescale is exp2(-huge) = 0)
+  float l = 0.f;
+  const float c = p.scale_log2e;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nt) stage(t + 1, cur ^ 1);
+    lds_char* const kt = smem + cur * G::kStageBytes;
+    lds_char* const vt = kt + G::kTileBytes;
+    if (t == nt - 1 && (N % kBc) != 0) {
+      tile_compute<D, true>(kt, vt, qf, o, m, l, c, t * kBc, N, lane);
+    } else {
+      tile_compute<D, false>(kt, vt, qf, o, m, l, c, t * kBc, N, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: O = O^T / l, registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 ----------
+  const HalfPair lp = both_halves(l);
+  const float inv = 1.0f / (lp.lo + lp.hi);
+#pragma unroll
+  for (int b = 0; b < G::kDvBlocks; ++b) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dv = 32 * b + 8 * g + 4 * h;
+      if constexpr (FAST) {
+        f16x4 pk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = (f16)(o[b][4 * g + j] * inv);
+        const uint32_t off = (dv < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), o_rs, off, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t off =
+              (dv + j < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)(dv + j)) * (uint32_t)sizeof(T) : kOob;
+          store_elem(o_rs, off, (T)(o[b][4 * g + j] * inv));
+        }
+      }
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+}  // namespace flash_hip

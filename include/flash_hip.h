@@ -1,0 +1,117 @@
+/*
+ * flash_hip.h — C ABI of the MI355X (gfx950) attention-forward library, libflash_hip.so.
+ *
+ * This is the drop-in boundary for the one hot path of ishovkun/flash-attention: everything the
+ * reference does between `flash::forward` reading the tensor shapes and `cudaDeviceSynchronize`
+ * (reference flash/launch.cu:185-324).  Plain pointers and sizes only; no torch types.  The
+ * reference's C++/torch surface (flash::forward, KernelParameters, pyflash) is re-created on top of
+ * these entry points under flash-attention_amd/flash and flash-attention_amd/pyflash.
+ *
+ * Conventions
+ *   - All tensors are contiguous [B, H, N, d] (reference flash/kernel_mma_qreg.cuh:30-34:
+ *     qkv_offset = (b*H + h)*N*d); K and V have the shape of Q; O has the shape of Q.
+ *   - Device = the calling thread's current HIP device.  `hip_stream` is a hipStream_t (NULL = the
+ *     default stream).  Calls enqueue work and return; they never synchronise, allocate or free.
+ *   - Return value: FLASH_HIP_OK (0) or a negative flash_hip_status.  The text of the last error of
+ *     the calling thread is available from flash_hip_last_error().
+ *   - kernel_type is the integer value of the reference's `enum class KernelType`
+ *     (reference flash/launch.hpp:7-20), 0..11.
+ */
+#ifndef FLASH_HIP_H_
+#define FLASH_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum flash_hip_status {
+  FLASH_HIP_OK = 0,
+  FLASH_HIP_ERR_INVALID_ARGUMENT = -1, /* maps to std::invalid_argument (launch.cu:79-85,267-269,284-286,301-303,317) */
+  FLASH_HIP_ERR_UNSUPPORTED_DIM = -2,  /* head dim has no compiled tile; std::invalid_argument in the reference (launch.cu:270-280) */
+  FLASH_HIP_ERR_RUNTIME = -3,          /* HIP runtime error; reference prints and exits (launch.cu:63-77) */
+  FLASH_HIP_ERR_LDS = -4               /* dynamic LDS request rejected; std::runtime_error in the reference (launch.cu:141-147) */
+} flash_hip_status;
+
+/* Integer values of the reference's KernelType (flash/launch.hpp:7-20). */
+typedef enum flash_hip_kernel_type {
+  FLASH_KT_NAIVE1D = 0,
+  FLASH_KT_SCALAR2D = 1,
+  FLASH_KT_SCALAR2D_ROW_TILE = 2,
+  FLASH_KT_WARP_WMMA = 3,
+  FLASH_KT_BLOCK_WMMA = 4,
+  FLASH_KT_WMMA_ROW_BLOCK = 5,
+  FLASH_KT_BLOCK_WMMA_ASYNC = 6,
+  FLASH_KT_MMA = 7,
+  FLASH_KT_MMA_SWIZZLE = 8,
+  FLASH_KT_MMA_QREG = 9,
+  FLASH_KT_MMA_QREG_F32X4LOAD = 10,
+  FLASH_KT_MMA_QREG_ASYNC = 11,
+  FLASH_KT_COUNT = 12
+} flash_hip_kernel_type;
+
+/*
+ * Launch geometry of one call, the data the reference exposes through KernelParametersBase
+ * (flash/KernelParameters.hpp:63-71: tileSize / sramSize / blockDim / gridDim).
+ */
+typedef struct flash_launch_info {
+  uint32_t tile_kv;      /* Bc: K/V rows per LDS tile                (tileSize().x) */
+  uint32_t tile_q;       /* Br: Q rows per workgroup                 (tileSize().y) */
+  uint32_t tile_d;       /* head dim padded to the compiled tile     (tileSize().z) */
+  uint32_t lds_bytes;    /* dynamic LDS per workgroup                (sramSize())   */
+  uint32_t block_x;      /* lanes per wave = 64                      (blockDim().x) */
+  uint32_t block_y;      /* waves per workgroup                      (blockDim().y) */
+  uint32_t grid_x;       /* B                                        (gridDim().x)  */
+  uint32_t grid_y;       /* H                                        (gridDim().y)  */
+  uint32_t grid_z;       /* ceil(N / Br)                             (gridDim().z)  */
+  uint32_t staging;      /* 0 = register-staged element loads, 1 = register-staged 128-bit loads,
+                            2 = direct global->LDS loads (buffer_load ... lds) */
+  uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */
+} flash_launch_info;
+
+/*
+ * fp16 attention forward: O = softmax(Q K^T * softmax_scale) V per (b, h), non-causal, no mask.
+ * Replaces the body of the reference's flash::forward after tensor unpacking
+ * (flash/launch.cu:197-204 KernelArgs, :216-318 dispatch, :130-183 launchKernel) and the kernels
+ * kernel_mma_qreg / _f32x4load / _async (flash/kernel_mma_qreg*.cuh).
+ * q, k, v, o: device pointers to IEEE binary16 data.  fp16 operands, fp32 accumulation.
+ * Errors mirror the reference: d > 128 -> UNSUPPORTED_DIM; kernel_type 9 needs d % 2 == 0, 10 and
+ * 11 need d % 4 == 0 -> INVALID_ARGUMENT; unknown kernel_type -> INVALID_ARGUMENT.
+ */
+int flash_fwd_f16(const void* q, const void* k, const void* v, void* o,
+                  int64_t B, int64_t H, int64_t N, int64_t d,
+                  float softmax_scale, int kernel_type, void* hip_stream);
+
+/*
+ * fp32 attention forward for the reference's fp32 callers (main.cpp:30-32, benchmarks/bench.py:34-36
+ * hand fp32 tensors to flash::forward, which reads them with data_ptr<float>(), launch.cu:165-176).
+ * Q, K, V are rounded to fp16 (round-to-nearest-even) while they are staged into LDS/registers, the
+ * arithmetic is the same fp16-MFMA / fp32-accumulate pipeline, O is written as fp32.
+ */
+int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
+                  int64_t B, int64_t H, int64_t N, int64_t d,
+                  float softmax_scale, int kernel_type, void* hip_stream);
+
+/*
+ * Geometry query; does not touch the GPU.  Replaces KernelParametersFactory::create
+ * (flash/KernelParameters.hpp:383-422) for the native kernel.  Same error codes as flash_fwd_f16.
+ */
+int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type,
+                    flash_launch_info* out);
+
+/* Name of a kernel type as the reference's to_string prints it (flash/launch.hpp:28-46); NULL if
+ * out of range. */
+const char* flash_kernel_type_name(int kernel_type);
+
+/* Last error text of the calling thread ("" if none).  The pointer stays valid until the next
+ * failing call on the same thread. */
+const char* flash_hip_last_error(void);
+
+/* Library version, major*10000 + minor*100 + patch. */
+int flash_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASH_HIP_H_ */

@@ -1,0 +1,243 @@
+// Native parity + timing harness for libflash_hip.so (no Python, no torch).
+// Calls the library through its C ABI only and checks the result against the CPU oracle
+// (oracle/attention_oracle.c), on the reference runner's shapes (reference main.cpp:157-193) plus
+// larger ones.  Usage:
+//   selftest                 parity on the built-in shape list (fp16 and fp32 entry points)
+//   selftest bench B H N d [reps] [kernel_type]   hipEvent timing of one shape, parity on 4 sample heads
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/flash_hip.h"
+
+extern "C" {
+int oracle_attn_naive(const float* q, const float* k, const float* v, float* o, int64_t B, int64_t H, int64_t N,
+                      int64_t d, float scale);
+void oracle_f32_to_f16_bits(const float* in, uint16_t* out, int64_t n);
+void oracle_f16_bits_to_f32(const uint16_t* in, float* out, int64_t n);
+}
+
+#define HIP_CHECK(x)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (x);                                                                 \
+    if (e_ != hipSuccess) {                                                              \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                           \
+    }                                                                                    \
+  } while (0)
+
+static uint64_t g_state = 0x9E3779B97F4A7C15ull;
+static inline double urand() {
+  g_state = g_state * 6364136223846793005ull + 1442695040888963407ull;
+  return ((g_state >> 11) + 0.5) / 9007199254740992.0;
+}
+static void fill_normal(std::vector<float>& x) {
+  for (size_t i = 0; i + 1 < x.size(); i += 2) {
+    const double u1 = urand(), u2 = urand();
+    const double rad = std::sqrt(-2.0 * std::log(u1));
+    x[i] = (float)(rad * std::cos(6.283185307179586 * u2));
+    x[i + 1] = (float)(rad * std::sin(6.283185307179586 * u2));
+  }
+  if (x.size() & 1) x.back() = (float)(std::sqrt(-2.0 * std::log(urand())) * std::cos(6.283185307179586 * urand()));
+}
+
+struct Cmp {
+  double max_abs = 0, max_rel = 0;
+  size_t bad = 0, nan = 0;
+};
+// |res - ref| <= atol + rtol*|ref| (reference main.cpp:49), atol 2e-3, rtol 1e-2
+static Cmp compare(const float* res, const float* ref, size_t n) {
+  Cmp c;
+  for (size_t i = 0; i < n; ++i) {
+    if (std::isnan(res[i])) {
+      c.nan++;
+      c.bad++;
+      continue;
+    }
+    const double e = std::fabs((double)res[i] - (double)ref[i]);
+    c.max_abs = std::max(c.max_abs, e);
+    c.max_rel = std::max(c.max_rel, e / (std::fabs((double)ref[i]) + 1e-2));
+    if (e > 2e-3 + 1e-2 * std::fabs((double)ref[i])) c.bad++;
+  }
+  return c;
+}
+
+static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool fp32_io) {
+  const size_t n = (size_t)(B * H * N * d);
+  std::vector<float> q(n), k(n), v(n), qr(n), kr(n), vr(n), ref(n), out(n);
+  fill_normal(q);
+  fill_normal(k);
+  fill_normal(v);
+  std::vector<uint16_t> qh(n), kh(n), vh(n), oh(n);
+  oracle_f32_to_f16_bits(q.data(), qh.data(), n);
+  oracle_f32_to_f16_bits(k.data(), kh.data(), n);
+  oracle_f32_to_f16_bits(v.data(), vh.data(), n);
+  oracle_f16_bits_to_f32(qh.data(), qr.data(), n);
+  oracle_f16_bits_to_f32(kh.data(), kr.data(), n);
+  oracle_f16_bits_to_f32(vh.data(), vr.data(), n);
+  const float scale = 1.0f / std::sqrt((float)d);
+  oracle_attn_naive(qr.data(), kr.data(), vr.data(), ref.data(), B, H, N, d, scale);
+
+  const size_t esz = fp32_io ? 4 : 2;
+  void *dq, *dk, *dv, *dout;
+  HIP_CHECK(hipMalloc(&dq, n * esz));
+  HIP_CHECK(hipMalloc(&dk, n * esz));
+  HIP_CHECK(hipMalloc(&dv, n * esz));
+  HIP_CHECK(hipMalloc(&dout, n * esz));
+  if (fp32_io) {
+    // fp32 callers hand over unrounded data; the kernel rounds to fp16 itself
+    HIP_CHECK(hipMemcpy(dq, q.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dk, k.data(), n * 4, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dv, v.data(), n * 4, hipMemcpyHostToDevice));
+  } else {
+    HIP_CHECK(hipMemcpy(dq, qh.data(), n * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dk, kh.data(), n * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dv, vh.data(), n * 2, hipMemcpyHostToDevice));
+  }
+  HIP_CHECK(hipMemset(dout, 0xff, n * esz));  // NaN pattern: unwritten outputs show up
+  int rc = fp32_io ? flash_fwd_f32(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr)
+                   : flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
+  bool ok = true;
+  if (rc != FLASH_HIP_OK) {
+    printf("  launch failed rc=%d: %s\n", rc, flash_hip_last_error());
+    ok = false;
+  } else {
+    HIP_CHECK(hipDeviceSynchronize());
+    if (fp32_io) {
+      HIP_CHECK(hipMemcpy(out.data(), dout, n * 4, hipMemcpyDeviceToHost));
+    } else {
+      HIP_CHECK(hipMemcpy(oh.data(), dout, n * 2, hipMemcpyDeviceToHost));
+      oracle_f16_bits_to_f32(oh.data(), out.data(), n);
+    }
+    Cmp c = compare(out.data(), ref.data(), n);
+    ok = c.bad == 0 && c.max_abs <= 2e-3;
+    printf("  (%lld,%lld,%lld,%lld) %-18s %s  max_abs=%.3e max_rel=%.3e bad=%zu nan=%zu  %s\n", (long long)B,
+           (long long)H, (long long)N, (long long)d, flash_kernel_type_name(kt), fp32_io ? "f32" : "f16", c.max_abs,
+           c.max_rel, c.bad, c.nan, ok ? "PASS" : "FAIL");
+    if (!ok) {
+      int shown = 0;
+      for (size_t i = 0; i < n && shown < 7; ++i) {
+        const double e = std::fabs((double)out[i] - (double)ref[i]);
+        if (std::isnan(out[i]) || e > 2e-3 + 1e-2 * std::fabs((double)ref[i])) {
+          const size_t x = i % d, row = (i / d) % N, hd = i / (d * N);
+          printf("    mismatch[head %zu, row %zu, col %zu] ref=%g res=%g\n", hd, row, x, ref[i], out[i]);
+          shown++;
+        }
+      }
+    }
+  }
+  HIP_CHECK(hipFree(dq));
+  HIP_CHECK(hipFree(dk));
+  HIP_CHECK(hipFree(dv));
+  HIP_CHECK(hipFree(dout));
+  return ok;
+}
+
+static int bench_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps, int kt) {
+  const size_t per_head = (size_t)(N * d);
+  const size_t n = (size_t)(B * H) * per_head;
+  // random data for every head: generate 8 distinct heads and tile them (keeps host time bounded)
+  const int64_t gen_heads = std::min<int64_t>(8, B * H);
+  std::vector<float> q(gen_heads * per_head), k(q.size()), v(q.size());
+  fill_normal(q);
+  fill_normal(k);
+  fill_normal(v);
+  std::vector<uint16_t> qh(q.size()), kh(q.size()), vh(q.size());
+  oracle_f32_to_f16_bits(q.data(), qh.data(), q.size());
+  oracle_f32_to_f16_bits(k.data(), kh.data(), q.size());
+  oracle_f32_to_f16_bits(v.data(), vh.data(), q.size());
+  uint16_t *dq, *dk, *dv, *dout;
+  HIP_CHECK(hipMalloc(&dq, n * 2));
+  HIP_CHECK(hipMalloc(&dk, n * 2));
+  HIP_CHECK(hipMalloc(&dv, n * 2));
+  HIP_CHECK(hipMalloc(&dout, n * 2));
+  for (int64_t hd = 0; hd < B * H; ++hd) {
+    const size_t src = (size_t)(hd % gen_heads) * per_head;
+    HIP_CHECK(hipMemcpy(dq + hd * per_head, qh.data() + src, per_head * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dk + hd * per_head, kh.data() + src, per_head * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dv + hd * per_head, vh.data() + src, per_head * 2, hipMemcpyHostToDevice));
+  }
+  const float scale = 1.0f / std::sqrt((float)d);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) {
+    int rc = flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
+    if (rc) {
+      printf("launch failed: %s\n", flash_hip_last_error());
+      return 1;
+    }
+  }
+  HIP_CHECK(hipDeviceSynchronize());
+  std::vector<float> times;
+  for (int i = 0; i < reps; ++i) {
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    times.push_back(ms);
+  }
+  std::sort(times.begin(), times.end());
+  const double med = times[times.size() / 2], mn = times[0];
+  const double flops = 4.0 * B * H * (double)N * (double)N * d;
+  printf("bench (%lld,%lld,%lld,%lld) %s: median %.4f ms  min %.4f ms  -> %.1f TFLOP/s (median), %.1f (best)\n",
+         (long long)B, (long long)H, (long long)N, (long long)d, flash_kernel_type_name(kt), med, mn,
+         flops / med * 1e-9, flops / mn * 1e-9);
+  // parity on the first and last generated heads as they sit at the end of the tensor
+  bool ok = true;
+  if (N <= 4096) {
+    const int64_t hd = B * H - 1;
+    const size_t src = (size_t)(hd % gen_heads) * per_head;
+    std::vector<float> qr(per_head), kr(per_head), vr(per_head), ref(per_head), out(per_head);
+    oracle_f16_bits_to_f32(qh.data() + src, qr.data(), per_head);
+    oracle_f16_bits_to_f32(kh.data() + src, kr.data(), per_head);
+    oracle_f16_bits_to_f32(vh.data() + src, vr.data(), per_head);
+    oracle_attn_naive(qr.data(), kr.data(), vr.data(), ref.data(), 1, 1, N, d, scale);
+    std::vector<uint16_t> oh(per_head);
+    HIP_CHECK(hipMemcpy(oh.data(), dout + hd * per_head, per_head * 2, hipMemcpyDeviceToHost));
+    oracle_f16_bits_to_f32(oh.data(), out.data(), per_head);
+    Cmp c = compare(out.data(), ref.data(), per_head);
+    ok = c.bad == 0;
+    printf("  parity (last head): max_abs=%.3e max_rel=%.3e bad=%zu nan=%zu %s\n", c.max_abs, c.max_rel, c.bad, c.nan,
+           ok ? "PASS" : "FAIL");
+  }
+  return ok ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 6 && std::string(argv[1]) == "bench") {
+    const int reps = argc > 6 ? atoi(argv[6]) : 20;
+    const int kt = argc > 7 ? atoi(argv[7]) : FLASH_KT_MMA_QREG_ASYNC;
+    return bench_shape(atoll(argv[2]), atoll(argv[3]), atoll(argv[4]), atoll(argv[5]), reps, kt);
+  }
+  struct Shape {
+    int64_t B, H, N, d;
+  };
+  // the reference runner's five shapes (main.cpp:157-193), the tiny plumbing config, and shapes that
+  // cross tile boundaries of the native kernel (Br = 256, Bc = 64)
+  const Shape shapes[] = {{1, 1, 50, 32},  {1, 1, 100, 32},  {1, 1, 64, 50},   {5, 12, 53, 69}, {1, 1, 30, 128},
+                          {2, 4, 256, 64}, {2, 3, 300, 128}, {1, 2, 1024, 128}, {3, 2, 577, 64}, {1, 2, 257, 96},
+                          {1, 1, 1, 8},    {1, 3, 129, 40},  {2, 2, 511, 120}};
+  bool all = true;
+  for (const Shape& s : shapes) {
+    printf("shape (%lld,%lld,%lld,%lld)\n", (long long)s.B, (long long)s.H, (long long)s.N, (long long)s.d);
+    const int kts[] = {FLASH_KT_NAIVE1D, FLASH_KT_MMA_QREG, FLASH_KT_MMA_QREG_F32X4LOAD, FLASH_KT_MMA_QREG_ASYNC};
+    for (int kt : kts) {
+      if (kt == FLASH_KT_MMA_QREG && s.d % 2) continue;  // reference guards, main.cpp:114-126
+      if ((kt == FLASH_KT_MMA_QREG_F32X4LOAD || kt == FLASH_KT_MMA_QREG_ASYNC) && s.d % 4) continue;
+      all &= run_shape(s.B, s.H, s.N, s.d, kt, false);
+    }
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, true);
+  }
+  printf(all ? "ALL PASS\n" : "SOME FAILED\n");
+  return all ? 0 : 1;
+}
