@@ -1,0 +1,230 @@
+"""flash-attention for MI355X (gfx950): Python host side of the attention-forward hot path.
+
+This package is the Python mirror of the reference's operator surface for the one path it
+accelerates (reference flash/launch.hpp:7-24 ``KernelType`` / ``flash::forward``,
+flash/KernelParameters.hpp:63-71,383-422 launch geometry, pyflash/pyflash.cpp:10-35 torch ops).
+All arithmetic happens in ``lib/libflash_hip.so`` (hand-written HIP, C ABI in include/flash_hip.h);
+torch is used for device memory and streams only.  There is no CPU fallback: if the library is
+missing or there is no GPU, calls raise.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("flash-attention_amd")`` with the repository root on ``sys.path``.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libflash_hip.so")
+PYFLASH_PATH = os.path.join(REPO_ROOT, "build", "pyflash", "libpyflash.so")
+RUNNER_PATH = os.path.join(REPO_ROOT, "build", "runner")
+
+
+class KernelType(enum.IntEnum):
+    """Same members, same order as the reference's ``enum class KernelType`` (flash/launch.hpp:7-20)."""
+
+    naive1D = 0
+    scalar2D = 1
+    scalar2D_row_tile = 2
+    warp_wmma = 3
+    block_wmma = 4
+    wmma_row_block = 5
+    block_wmma_async = 6
+    mma = 7
+    mma_swizzle = 8
+    mma_qreg = 9
+    mma_qreg_f32x4load = 10
+    mma_qreg_async = 11
+
+
+# flash_hip_status (include/flash_hip.h)
+_OK, _EINVAL, _EDIM, _ERUNTIME, _ELDS = 0, -1, -2, -3, -4
+
+
+class _LaunchInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in (
+        "tile_kv", "tile_q", "tile_d", "lds_bytes", "block_x", "block_y",
+        "grid_x", "grid_y", "grid_z", "staging", "aligned_rows")]
+
+
+@dataclass(frozen=True)
+class LaunchInfo:
+    """What the reference's KernelParametersBase reports (flash/KernelParameters.hpp:63-71)."""
+
+    tile_size: Tuple[int, int, int]   # (Bc, Br, padded head dim)  == tileSize()
+    sram_size: int                    # dynamic LDS bytes          == sramSize()
+    block_dim: Tuple[int, int]        # (64 lanes, waves)          == blockDim()
+    grid_dim: Tuple[int, int, int]    # (B, H, ceil(N/Br))         == gridDim()
+    staging: int
+    aligned_rows: bool
+
+
+# every symbol include/flash_hip.h declares
+ABI_SYMBOLS = (
+    "flash_fwd_f16", "flash_fwd_f32", "flash_fwd_query", "flash_kernel_type_name",
+    "flash_hip_last_error", "flash_hip_version",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libflash_hip.so (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the attention kernel.")
+    # torch bundles its own HIP runtime (same soname); importing it first makes this process use
+    # exactly one copy of it.
+    import torch  # noqa: F401
+
+    L = ctypes.CDLL(LIB_PATH)
+    i64, vp = ctypes.c_int64, ctypes.c_void_p
+    for name in ("flash_fwd_f16", "flash_fwd_f32"):
+        fn = getattr(L, name)
+        fn.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_int, vp]
+        fn.restype = ctypes.c_int
+    L.flash_fwd_query.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.POINTER(_LaunchInfo)]
+    L.flash_fwd_query.restype = ctypes.c_int
+    L.flash_kernel_type_name.argtypes = [ctypes.c_int]
+    L.flash_kernel_type_name.restype = ctypes.c_char_p
+    L.flash_hip_last_error.argtypes = []
+    L.flash_hip_last_error.restype = ctypes.c_char_p
+    L.flash_hip_version.argtypes = []
+    L.flash_hip_version.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _raise(rc: int) -> None:
+    msg = lib().flash_hip_last_error().decode("utf-8", "replace")
+    # std::invalid_argument in the reference (flash/launch.cu:79-85,267-269,284-286,317) -> ValueError
+    if rc in (_EINVAL, _EDIM):
+        raise ValueError(msg)
+    raise RuntimeError(msg)  # std::runtime_error / gpuErrchk in the reference (launch.cu:63-77,146)
+
+
+def to_string(kernel_type) -> str:
+    """Reference ``to_string(flash::KernelType)`` (flash/launch.hpp:28-46)."""
+    name = lib().flash_kernel_type_name(int(kernel_type))
+    if name is None:
+        raise ValueError("wrong kernel type")
+    return name.decode()
+
+
+def launch_info(B: int, H: int, N: int, d: int, kernel_type=KernelType.mma_qreg_async) -> LaunchInfo:
+    """Counterpart of ``KernelParametersFactory::create`` (flash/KernelParameters.hpp:383-422)."""
+    info = _LaunchInfo()
+    rc = lib().flash_fwd_query(B, H, N, d, int(kernel_type), ctypes.byref(info))
+    if rc != _OK:
+        _raise(rc)
+    return LaunchInfo(
+        tile_size=(info.tile_kv, info.tile_q, info.tile_d), sram_size=info.lds_bytes,
+        block_dim=(info.block_x, info.block_y), grid_dim=(info.grid_x, info.grid_y, info.grid_z),
+        staging=info.staging, aligned_rows=bool(info.aligned_rows))
+
+
+def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: bool = True):
+    """Counterpart of ``flash::forward(Q, K, V, kernel_type)`` (flash/launch.hpp:23-24).
+
+    Q, K, V: 4-D ``[B, H, N, d]`` tensors on a HIP device, fp16 (native) or fp32 (the reference's
+    dtype; rounded to fp16 inside the kernel, result returned as fp32).  Returns a new tensor O of
+    the shape and dtype of Q.  Like the reference (flash/launch.cu:320-321) the call blocks until
+    the kernel has finished unless ``sync=False``.
+    """
+    import torch
+
+    if Q.dim() != 4:
+        raise ValueError("Q must be [B, H, N, d]")
+    if K.shape != Q.shape or V.shape != Q.shape:
+        raise ValueError("K and V must have the shape of Q")
+    if not Q.is_cuda or K.device != Q.device or V.device != Q.device:
+        raise ValueError("Q, K, V must live on the same HIP device (there is no CPU path)")
+    if Q.dtype not in (torch.float16, torch.float32) or K.dtype != Q.dtype or V.dtype != Q.dtype:
+        raise ValueError("Q, K, V must all be float16 or all be float32")
+    Q, K, V = Q.contiguous(), K.contiguous(), V.contiguous()
+    B, H, N, d = Q.shape
+    if out is None:
+        out = torch.empty_like(Q)  # write-only for this kernel; the reference needs zeros (launch.cu:195)
+    elif out.shape != Q.shape or out.dtype != Q.dtype or not out.is_contiguous() or out.device != Q.device:
+        raise ValueError("out must be a contiguous tensor like Q")
+    fn = lib().flash_fwd_f16 if Q.dtype == torch.float16 else lib().flash_fwd_f32
+    with torch.cuda.device(Q.device):
+        stream = torch.cuda.current_stream(Q.device)
+        rc = fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d,
+                1.0 / float(d) ** 0.5, int(kernel_type), ctypes.c_void_p(stream.cuda_stream))
+        if rc != _OK:
+            _raise(rc)
+        if sync:
+            stream.synchronize()
+    return out
+
+
+def load_pyflash() -> None:
+    """``torch.ops.load_library(build/pyflash/libpyflash.so)`` as the reference's benchmark does
+    (benchmarks/bench.py:12-14); afterwards ``torch.ops.pyflash.<name>(q, k, v)`` is available."""
+    import torch
+
+    if not os.path.exists(PYFLASH_PATH):
+        raise ImportError(f"{PYFLASH_PATH} not found: run __graft_entry__.build()")
+    torch.ops.load_library(PYFLASH_PATH)
+
+
+# ---- batch x heads sharding across GPUs (one process per GPU) -------------------------------------
+def shard_heads(total_heads: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slab [start, stop) of the flattened batch*heads axis owned by ``rank``.
+
+    Heads are independent (reference flash/kernel_mma_qreg.cuh:30-34: one block per (batch, head),
+    offset (b*H + h)*N*d), and the layout is [B, H, N, d], so a slab of consecutive flattened heads
+    is one contiguous byte range.  Slab size is ceil(total/world); the last ranks may own fewer (or
+    zero) heads.
+    """
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    per = -(-total_heads // world_size)
+    start = min(rank * per, total_heads)
+    stop = min(start + per, total_heads)
+    return start, stop
+
+
+def forward_shard(Qs, Ks, Vs, kernel_type=KernelType.mma_qreg_async, *, sync: bool = True):
+    """Forward of this rank's slab.  ``Qs`` etc. are ``[heads_local, N, d]`` (the slab of the
+    flattened [B*H, N, d] tensor); no collective is involved."""
+    hl, N, d = Qs.shape
+    out = forward(Qs.view(1, hl, N, d), Ks.view(1, hl, N, d), Vs.view(1, hl, N, d), kernel_type, sync=sync)
+    return out.view(hl, N, d)
+
+
+def gather_output(O_local, total_heads: int, group=None):
+    """Optional output gather: all ranks receive the full ``[total_heads, N, d]`` O.
+
+    Uses ``torch.distributed.all_gather`` (RCCL over xGMI with the nccl backend, gloo on CPU) on
+    equally sized, zero-padded slabs; it is outside the attention hot loop and only needed by
+    callers that want O replicated.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per = -(-total_heads // world)
+    pad = per - O_local.shape[0]
+    if pad:
+        O_local = torch.cat([O_local, O_local.new_zeros((pad,) + tuple(O_local.shape[1:]))], dim=0)
+    bufs = [torch.empty_like(O_local) for _ in range(world)]
+    dist.all_gather(bufs, O_local.contiguous(), group=group)
+    return torch.cat(bufs, dim=0)[:total_heads]
+
+
+__all__ = [
+    "KernelType", "LaunchInfo", "ABI_SYMBOLS", "lib", "to_string", "launch_info", "forward",
+    "load_pyflash", "shard_heads", "forward_shard", "gather_output",
+    "LIB_PATH", "PYFLASH_PATH", "RUNNER_PATH", "REPO_ROOT",
+]

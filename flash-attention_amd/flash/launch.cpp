@@ -1,0 +1,82 @@
+// flash::forward on MI355X: tensor checks, output allocation, one call into the C ABI
+// (include/flash_hip.h), stream synchronisation.  Replaces the body of the reference's
+// flash::forward (reference flash/launch.cu:185-324); the template dispatch and launchKernel of the
+// reference (:130-183, :216-318) live behind flash_fwd_f16 / flash_fwd_f32.
+#include "launch.hpp"
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <iostream>
+
+#include "../../include/flash_hip.h"
+#include "KernelParameters.hpp"
+
+namespace flash {
+
+namespace {
+
+void check_inputs(const torch::Tensor& Q, const torch::Tensor& K, const torch::Tensor& V) {
+  TORCH_CHECK(Q.dim() == 4, "flash::forward: Q must be [B, H, N, d], got ", Q.dim(), " dims");
+  TORCH_CHECK(K.sizes() == Q.sizes() && V.sizes() == Q.sizes(), "flash::forward: K and V must have the shape of Q");
+  TORCH_CHECK(Q.is_cuda() && K.is_cuda() && V.is_cuda(), "flash::forward: tensors must be on a HIP device");
+  TORCH_CHECK(K.device() == Q.device() && V.device() == Q.device(), "flash::forward: tensors on different devices");
+  TORCH_CHECK(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kFloat,
+              "flash::forward: dtype must be float16 or float32");
+  TORCH_CHECK(K.scalar_type() == Q.scalar_type() && V.scalar_type() == Q.scalar_type(),
+              "flash::forward: Q, K, V must share one dtype");
+}
+
+torch::Tensor run(torch::Tensor Q, torch::Tensor K, torch::Tensor V, KernelType kernel_type, bool wait) {
+  check_inputs(Q, K, V);
+  Q = Q.contiguous();
+  K = K.contiguous();
+  V = V.contiguous();
+  const int64_t B = Q.size(0);   // batch size
+  const int64_t H = Q.size(1);   // number of heads
+  const int64_t N = Q.size(2);   // sequence length
+  const int64_t d = Q.size(3);   // head dimension
+  const float softmax_scale = 1.0f / std::sqrt(static_cast<float>(d));
+
+  // The geometry object is not needed to launch, but constructing it keeps the reference's
+  // behaviour of rejecting unsupported shapes before anything is allocated.
+  auto params = KernelParametersFactory::create(static_cast<int>(B), static_cast<int>(H), static_cast<int>(N),
+                                                static_cast<int>(d), kernel_type);
+  (void)params;
+
+  const c10::hip::HIPGuard guard(Q.device());
+  auto O = torch::empty_like(Q);  // every element is written by the kernel
+  const c10::hip::HIPStream stream = c10::hip::getCurrentHIPStream(Q.device().index());
+  const int kt = static_cast<int>(kernel_type);
+  const int rc = Q.scalar_type() == at::kHalf
+                     ? flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale,
+                                     kt, stream.stream())
+                     : flash_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale,
+                                     kt, stream.stream());
+  if (rc == FLASH_HIP_ERR_INVALID_ARGUMENT || rc == FLASH_HIP_ERR_UNSUPPORTED_DIM)
+    throw std::invalid_argument(flash_hip_last_error());
+  if (rc != FLASH_HIP_OK) throw std::runtime_error(flash_hip_last_error());
+  if (wait) {
+    const hipError_t e = hipStreamSynchronize(stream.stream());
+    if (e != hipSuccess) {
+      // the reference prints and exits on a device error (flash/launch.cu:68-77)
+      std::cerr << "GPUassert: " << hipGetErrorString(e) << " " << __FILE__ << " " << __LINE__ << std::endl;
+      std::exit(static_cast<int>(e));
+    }
+  }
+  return O;
+}
+
+}  // namespace
+
+torch::Tensor forward(torch::Tensor Q, torch::Tensor K, torch::Tensor V, KernelType kernel_type) {
+  return run(std::move(Q), std::move(K), std::move(V), kernel_type, /*wait=*/true);
+}
+
+torch::Tensor forward_async(torch::Tensor Q, torch::Tensor K, torch::Tensor V, KernelType kernel_type) {
+  return run(std::move(Q), std::move(K), std::move(V), kernel_type, /*wait=*/false);
+}
+
+}  // namespace flash

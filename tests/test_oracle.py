@@ -1,0 +1,77 @@
+"""CPU only: the oracle (oracle/attention_oracle.c) against the golden vectors and against itself."""
+import numpy as np
+import pytest
+
+from conftest import RUNNER_SHAPES, TINY_SHAPE, load_golden
+
+ALL = RUNNER_SHAPES + [TINY_SHAPE]
+
+
+@pytest.mark.parametrize("shape", ALL, ids=str)
+def test_naive_matches_reference_oracle_fp32_inputs(oracle, shape):
+    """oracle_attn_naive == the reference's manual_attn (libtorch) on the reference's fp32 inputs."""
+    g = load_golden(shape)
+    o = oracle.attn_naive(g["q32"], g["k32"], g["v32"])
+    np.testing.assert_allclose(o, g["o_f32"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("shape", ALL, ids=str)
+def test_naive_matches_reference_oracle_fp16_inputs(oracle, shape):
+    g = load_golden(shape)
+    q, k, v = (g[n].astype(np.float32) for n in "qkv")
+    o = oracle.attn_naive(q, k, v)
+    np.testing.assert_allclose(o, g["o"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("shape", ALL, ids=str)
+def test_tiled_restatement_matches_golden(oracle, shape):
+    """The reference's tile loop (Br=128, Bc=64, per-tile renormalisation) gives the oracle's O, m, l."""
+    g = load_golden(shape)
+    q, k, v = (g[n].astype(np.float32) for n in "qkv")
+    o, m, l = oracle.attn_tiled(q, k, v, Br=128, Bc=64, return_ml=True)
+    np.testing.assert_allclose(o, g["o"], rtol=5e-5, atol=5e-6)
+    np.testing.assert_allclose(m, g["m"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(l, g["l"], rtol=5e-5, atol=0)
+
+
+@pytest.mark.parametrize("Br,Bc", [(256, 64), (32, 16), (7, 5), (128, 64)])
+def test_tiled_fp16_p_deferred_norm_within_bar(oracle, Br, Bc):
+    """The MI355X kernel's variant of the loop (fp16 P, normalise once) stays inside the parity bar."""
+    from conftest import assert_close
+
+    g = load_golden(TINY_SHAPE)
+    q, k, v = (g[n].astype(np.float32) for n in "qkv")
+    o = oracle.attn_tiled(q, k, v, Br=Br, Bc=Bc, p_f16=True, defer_norm=True)
+    assert_close(o, g["o"], f"tiled Br={Br} Bc={Bc}")
+
+
+def test_c_oracle_matches_float64_numpy(oracle):
+    rng = np.random.default_rng(1)
+    q, k, v = (rng.standard_normal((2, 3, 77, 24)).astype(np.float32) for _ in range(3))
+    np.testing.assert_allclose(oracle.attn_naive(q, k, v), oracle.attn_numpy(q, k, v), rtol=3e-5, atol=3e-6)
+
+
+def test_f16_rounding_matches_numpy(oracle):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([
+        rng.standard_normal(4096).astype(np.float32) * 10.0 ** rng.integers(-9, 6, 4096),
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, 5.96e-8, 2.98e-8, 2.99e-8, 6.1e-5, np.inf, -np.inf],
+                 dtype=np.float32),
+    ]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).astype(np.float32)
+    got = oracle.round_f16(x)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_edge_single_key_and_uniform(oracle):
+    # N = 1: softmax over one key is 1, O = V
+    q = np.ones((1, 1, 1, 8), np.float32)
+    v = np.arange(8, dtype=np.float32).reshape(1, 1, 1, 8)
+    np.testing.assert_allclose(oracle.attn_naive(q, q, v), v)
+    # Q = 0: uniform attention, O = mean(V)
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((1, 2, 33, 16)).astype(np.float32)
+    z = np.zeros_like(v)
+    o = oracle.attn_tiled(z, v, v, Br=8, Bc=8)
+    np.testing.assert_allclose(o, np.broadcast_to(v.mean(axis=2, keepdims=True), v.shape), rtol=1e-5, atol=1e-6)
