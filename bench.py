@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the attention-forward hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one forward pass of the native kernel over one synthetic batch that is already
+resident in HBM.  The default workload is the headline configuration of BASELINE.json's metric
+(fp16, B=4, H=96, N=4096, d=128); `--workload gpt3_1k` is configs[1] (N=1024) and `--workload
+d64` is the small-head configuration (16, 32, 2048, 64).  With N > 1 GPUs (launched through
+torch.distributed.run, one rank per GPU) every rank owns its own batch of the same shape — the
+batch x heads axis is what shards, there is no collective on the data path — so scaling is weak and
+`value` is the sum over ranks of FLOPs / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant kernel vs. the dense fp16 MFMA peak (HIP events on the launch stream)
+  cpu_baseline  the CPU oracle (OpenMP, fp32) timed on a bounded head sample of the same workload
+  parity        max-abs error of one head of the timed output against the CPU oracle
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (B, H, N, d)
+    "headline": (4, 96, 4096, 128),   # target shape of the metric: H=96, d=128, N=4096
+    "gpt3_1k": (4, 96, 1024, 128),    # BASELINE.json configs[1]
+    "gpt3_2k": (4, 96, 2048, 128),    # the reference runner's benchmark shape (main.cpp:197-202)
+    "d64": (16, 32, 2048, 64),        # configs[3]
+    "tiny": (2, 4, 256, 64),          # configs[0]
+}
+PEAK_TFLOPS_FP16_DENSE = 2500.0       # MI355X dense fp16/bf16 MFMA peak (256 CU x 4096 flop/clk x 2.4 GHz)
+
+
+def attention_flops(B, H, N, d):
+    return 4.0 * B * H * N * N * d    # QK^T + PV, non-causal
+
+
+def cpu_baseline(oracle, shape, budget_heads=4):
+    """Time the CPU oracle on `budget_heads` heads of the workload; report whole-workload-equivalent
+    TFLOP/s (heads are independent, so time scales linearly in B*H)."""
+    import numpy as np
+
+    B, H, N, d = shape
+    heads = min(budget_heads, B * H)
+    rng = np.random.default_rng(0)
+    q, k, v = (oracle.round_f16(rng.standard_normal((1, heads, N, d)).astype(np.float32)) for _ in range(3))
+    oracle.attn_naive(q[:, :1, :256], k[:, :1, :256], v[:, :1, :256])  # spin up the OpenMP pool
+    t0 = time.perf_counter()
+    oracle.attn_naive(q, k, v)
+    dt = time.perf_counter() - t0
+    return {
+        "value": attention_flops(1, heads, N, d) / dt / 1e12,
+        "unit": "TFLOP/s",
+        "cores": oracle.num_threads(),
+        "kind": "port",
+        "sample": f"{heads} of {B * H} heads of ({B},{H},{N},{d}), fp32 softmax(QK^T/sqrt(d))V, "
+                  f"{dt:.2f} s; whole workload would take {dt * B * H / heads:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel-type", default="mma_qreg_async")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    fa = importlib.import_module("flash-attention_amd")
+    fa.lib()  # fail loudly if the HIP library is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; there is no CPU path for the attention kernel")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    shape = WORKLOADS[args.workload]
+    B, H, N, d = shape
+    kt = fa.KernelType[args.kernel_type]
+    gen = torch.Generator(device=dev).manual_seed(rank)
+    q, k, v = (torch.randn(shape, device=dev, generator=gen).half() for _ in range(3))
+    o = torch.empty_like(q)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        fa.forward(q, k, v, kt, out=o, sync=False)
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # same stream the kernel is launched on (torch's current stream)
+    for _ in range(args.steps):
+        fa.forward(q, k, v, kt, out=o, sync=False)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        flops = attention_flops(*shape)
+        value = world * flops * args.steps / elapsed / 1e12
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        line = {
+            "metric": "attention fwd TFLOP/s (fp16, H=96 d=128) + % of MFMA peak at 1/2/4/8 GPUs",
+            "value": round(value, 2),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,       # the reference publishes no fp16 / MI355X number
+            "dtype": "fp16",
+            "data": "synthetic (standard normal, seeded per rank)",
+            "config": {
+                "workload": f"{args.workload}: attention forward B={B} H={H} N={N} d={d} per GPU, non-causal, "
+                            f"kernel_type={kt.name}",
+                "global_batch_heads": world * B * H,
+                "seq_len": N,
+                "head_dim": d,
+                "parallelism": f"batch*heads sharded over {world} GPU(s), no collective",
+            },
+            "pct_of_mfma_peak": round(100.0 * value / (world * PEAK_TFLOPS_FP16_DENSE), 2),
+            "roofline": {
+                "bound": "mfma",
+                "achieved": round(achieved, 2),
+                "peak": PEAK_TFLOPS_FP16_DENSE,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
+                "traffic": None,
+                "kernel": "flash_hip::attn_fwd_kernel",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_flops_per_launch": flops,
+            },
+        }
+        # parity of the timed output (one head) and the CPU baseline: rank 0, single-GPU runs only
+        if world == 1:
+            from oracle import oracle as orc
+
+            orc.build()
+            import numpy as np
+
+            hq, hk, hv = (x[B - 1:B, H - 1:H].float().cpu().numpy() for x in (q, k, v))
+            ref = orc.attn_naive(hq, hk, hv)
+            err = float(np.abs(o[B - 1, H - 1].float().cpu().numpy() - ref[0, 0]).max())
+            line["parity"] = {"max_abs_vs_cpu_oracle": err, "bar": 2e-3, "ok": bool(err <= 2e-3)}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(orc, shape)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

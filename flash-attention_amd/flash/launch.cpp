@@ -4,8 +4,8 @@
 // reference (:130-183, :216-318) live behind flash_fwd_f16 / flash_fwd_f32.
 #include "launch.hpp"
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <hip/hip_runtime_api.h>
 
 #include <cmath>
@@ -46,9 +46,11 @@ torch::Tensor run(torch::Tensor Q, torch::Tensor K, torch::Tensor V, KernelType 
                                                 static_cast<int>(d), kernel_type);
   (void)params;
 
-  const c10::hip::HIPGuard guard(Q.device());
+  // PyTorch-ROCm tensors carry the device type "cuda"; these are the guard and stream types that go
+  // with it.
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(Q.device());
   auto O = torch::empty_like(Q);  // every element is written by the kernel
-  const c10::hip::HIPStream stream = c10::hip::getCurrentHIPStream(Q.device().index());
+  const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(Q.device().index());
   const int kt = static_cast<int>(kernel_type);
   const int rc = Q.scalar_type() == at::kHalf
                      ? flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale,

@@ -18,7 +18,11 @@ torch::Tensor attention_op(torch::Tensor Q, torch::Tensor K, torch::Tensor V) {
 template <flash::KernelType KT>
 void bind(torch::Library& m, const char* op_name) {
   const std::string schema = std::string(op_name) + "(Tensor Q, Tensor K, Tensor V) -> Tensor";
-  m.def(schema.c_str(), torch::wrap_pybind_function(attention_op<KT>));
+  // A plain function pointer: C++ exceptions travel through the dispatcher to torch's Python
+  // binding, which translates them with the GIL held.  (The reference wraps the function with
+  // torch::wrap_pybind_function, whose error path touches the interpreter without the GIL when
+  // the op is invoked through torch.ops.)
+  m.def(schema.c_str(), &attention_op<KT>);
 }
 
 }  // namespace

@@ -126,12 +126,11 @@ def test_full_size_properties(fa, oracle, torch_gpu, shape):
 
     # (1) sampled heads against the CPU oracle (first, last, one in the middle)
     for (b, h) in [(0, 0), (B // 2, H // 3), (B - 1, H - 1)]:
-        rows = slice(0, N) if N <= 1024 else slice(N - 512, N)
         qs = q[b:b + 1, h:h + 1].float().cpu().numpy()
         ks = k[b:b + 1, h:h + 1].float().cpu().numpy()
         vs = v[b:b + 1, h:h + 1].float().cpu().numpy()
-        ref = oracle.attn_naive(qs[:, :, rows], ks, vs) if N > 1024 else oracle.attn_naive(qs, ks, vs)
-        assert_close(o[b, h, rows].float().cpu().numpy(), ref[0, 0], f"{shape} head ({b},{h})")
+        ref = oracle.attn_naive(qs, ks, vs)
+        assert_close(o[b, h].float().cpu().numpy(), ref[0, 0], f"{shape} head ({b},{h})")
 
     # (2) every output row is a convex combination of V rows: inside V's per-column range
     vmin = v.float().amin(dim=2, keepdim=True)
