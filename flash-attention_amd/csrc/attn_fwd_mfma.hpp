@@ -131,105 +131,127 @@ __device__ __forceinline__ void store_elem(__amdgpu_buffer_rsrc_t rs, uint32_t b
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rs, byte_off, 0, 0);
 }
 
-// ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T ----------------------------------
-// kt / vt: LDS addresses of the swizzled K and V tiles.  qf: this wave's Q fragments.
-// o: O^T accumulators (row = dv, col = query = lane & 31).  m: running max of the raw scores,
-// l: this lane's partial row sum (its half-wave's share of the keys).
-template <int D, bool MASK>
-__device__ __forceinline__ void tile_compute(lds_char* kt, lds_char* vt,
-                                             const f16x8 (&qf)[Geom<D>::kKSteps],
-                                             f32x16 (&o)[Geom<D>::kDvBlocks], float& m, float& l,
-                                             float c, int kv0, int N, int lane) {
+// ---- building blocks of the software pipeline -------------------------------------------------------
+// The unit of work is a BLOCK of 32 keys (half an LDS tile):
+//   qk_block       S^T(32 keys x 32 queries) = K_blk * Q^T            D/16 MFMAs
+//   softmax_block  running max, P^T = exp2(S^T*c - m*c) as fp16 B fragments, row-sum   (VALU only)
+//   pv_block       O^T += V_blk^T * P^T                                D/16 MFMAs
+// The kernel issues pv_block(j-1), qk_block(j+1) and softmax_block(j) of three consecutive blocks
+// next to each other; they are independent, so the matrix pipe and the vector ALU overlap.
+
+// S^T for the 32 keys that start at row `row0` of the K tile at `kt`.
+// Lane (r, h) reads K[row0 + r][16*ks + 8*h .. +8) as the A fragment of k-step ks.
+template <int D>
+__device__ __forceinline__ f32x16 qk_block(lds_char* kt, int row0, const f16x8 (&qf)[Geom<D>::kKSteps], int lane) {
   using G = Geom<D>;
   const int r = lane & 31;
   const int h = lane >> 5;
+  f32x16 s;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = 0.f;
+  f16x8 a[G::kKSteps];
+#pragma unroll
+  for (int ks = 0; ks < G::kKSteps; ++ks) a[ks] = *(FLASH_LDS_CAST(f16x8, kt + lds_off<D>(row0 + r, 2 * ks + h)));
+#pragma unroll
+  for (int ks = 0; ks < G::kKSteps; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], qf[ks], s, 0, 0, 0);
+  return s;
+}
 
-  // S^T blocks: keys kv0 + 32*blk + (reg&3) + 8*(reg>>2) + 4*h, query = r.
-  f32x16 s[2];
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[blk][i] = 0.f;
-  }
-#pragma unroll
-  for (int ks = 0; ks < G::kKSteps; ++ks) {
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      const f16x8 a = *(FLASH_LDS_CAST(f16x8, kt + lds_off<D>(blk * 32 + r, 2 * ks + h)));
-      s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[blk], 0, 0, 0);
-    }
-  }
-
-  if constexpr (MASK) {
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int kv = kv0 + blk * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (kv >= N) s[blk][i] = -INFINITY;
-      }
-    }
-  }
-
-  // row max over this lane's 32 keys, then over both half-waves
-  float mx = s[0][0];
-#pragma unroll
-  for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
-  const HalfPair mp = both_halves(mx);
-  const float m_new = fmaxf(m, fmaxf(mp.lo, mp.hi));
-
-  // rescale the running state to the new max (exp2 domain: c = scale * log2 e)
-  const float alpha = fast_exp2((m - m_new) * c);
-  m = m_new;
-  l *= alpha;
-#pragma unroll
-  for (int b = 0; b < G::kDvBlocks; ++b) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
-  }
-
-  // P^T = exp2(S^T * c - m * c), packed to fp16 B fragments (k-step = 8 consecutive registers)
-  const float mc = m_new * c;
-  f16x8 pf[4];
-  float rs = 0.f;
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float pv = fast_exp2(__builtin_fmaf(s[blk][i], c, -mc));
-      rs += pv;
-      pf[blk * 2 + (i >> 3)][i & 7] = (f16)pv;
-    }
-  }
-  l += rs;
-
-  // O^T[dv][q] += sum_kv V[kv][dv] * P[q][kv].  A operand = V^T via transposed LDS reads; element j
-  // of half-wave h of k-step ks is key 16*ks + 8*(j>>2) + 4*h + (j&3), the order P^T's registers
-  // already have.
+// O^T[dv][q] += sum_kv V[kv][dv] * P[q][kv] for the 32 keys at rows row0.. of the V tile at `vt`.
+// A operand = V^T through transposed LDS reads: element j of half-wave h of k-step ks is key
+// 16*ks + 8*(j>>2) + 4*h + (j&3), which is the order the registers of P^T already have.
+template <int D>
+__device__ __forceinline__ void pv_block(lds_char* vt, int row0, const f16x8 (&pf)[2],
+                                         f32x16 (&o)[Geom<D>::kDvBlocks], int lane) {
+  using G = Geom<D>;
+  const int h = lane >> 5;
   const int i16 = lane & 15;
-  const int tq = i16 >> 2;        // row of the 4x16 transposed block this lane addresses
-  const int tp = i16 & 3;         // 4-column group of that row
-  const int tg = (lane >> 4) & 1; // which 16 of the 32 dv columns
+  const int tq = i16 >> 2;         // row of the 4x16 transposed block this lane addresses
+  const int tp = i16 & 3;          // 4-column group of that row
+  const int tg = (lane >> 4) & 1;  // which 16 of the 32 dv columns
 #pragma unroll
   for (int b = 0; b < G::kDvBlocks; ++b) {
+    f16x8 a[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      f16x8 a;
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int row = 16 * ks + 8 * jj + 4 * h + tq;
+        const int row = row0 + 16 * ks + 8 * jj + 4 * h + tq;
         const int off = lds_off<D>(row, b * 4 + tg * 2 + (tp >> 1)) + 8 * (tp & 1);
         const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(FLASH_LDS_CAST(fp16x4_b, vt + off));
         const f16x4 tv = __builtin_bit_cast(f16x4, t);
-        a[4 * jj + 0] = tv[0];
-        a[4 * jj + 1] = tv[1];
-        a[4 * jj + 2] = tv[2];
-        a[4 * jj + 3] = tv[3];
+        a[ks][4 * jj + 0] = tv[0];
+        a[ks][4 * jj + 1] = tv[1];
+        a[ks][4 * jj + 2] = tv[2];
+        a[ks][4 * jj + 3] = tv[3];
       }
-      o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[ks], o[b], 0, 0, 0);
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], pf[ks], o[b], 0, 0, 0);
+  }
+}
+
+// Running softmax state of one lane: its query is lane & 31, its keys are those of its half-wave.
+struct SoftmaxState {
+  float m;      // reference max of the raw scores that P and O are currently scaled against
+  float l;      // this lane's partial row sum at that scale
+  float alpha;  // pending rescale factor for O (1 if none); applied by the caller after the
+                // previous block's P V product has been accumulated
+};
+
+// How far (in exp2 units, i.e. score * scale * log2 e) the row max may run ahead of `m` before the
+// state is rescaled.  P then stays below 2^kDeferLog2 = 256, far inside fp16 range, and O / l are
+// fp32, so the result is the same up to rounding; it saves the O-wide multiply on most blocks.
+constexpr float kDeferLog2 = 8.0f;
+
+// Softmax of one S^T block (keys kv0 + (i&3) + 8*(i>>2) + 4*h for register i).  Returns P^T as the
+// two fp16 B fragments of the block.  `masked`: keys >= N are excluded (wave-uniform flag).
+// Returns true (wave-uniform) when the caller has to multiply O by st.alpha.
+template <int D>
+__device__ __forceinline__ bool softmax_block(f32x16& s, f16x8 (&pf)[2], SoftmaxState& st, float c, int kv0, int N,
+                                              bool masked, int lane) {
+  const int h = lane >> 5;
+  if (masked) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kv = kv0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (kv >= N) s[i] = -INFINITY;
+    }
+  }
+  float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+  for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s[i], s[i + 1]));
+  const HalfPair mp = both_halves(mx);
+  mx = fmaxf(mp.lo, mp.hi);
+  // wave-uniform decision: rescale only if some row's max ran ahead of its reference by more than
+  // the deferral window (always true for the first block, where m is -huge)
+  const bool need = (mx - st.m) * c > kDeferLog2;
+  const bool rescale = __builtin_amdgcn_ballot_w64(need) != 0;
+  st.alpha = 1.0f;
+  if (rescale) {
+    const float m_new = fmaxf(st.m, mx);
+    st.alpha = fast_exp2((st.m - m_new) * c);
+    st.m = m_new;
+    st.l *= st.alpha;
+  }
+  const float mc = st.m * c;
+  float rs = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float pv = fast_exp2(__builtin_fmaf(s[i], c, -mc));
+    rs += pv;
+    pf[i >> 3][i & 7] = (f16)pv;
+  }
+  st.l += rs;
+  return rescale;
+}
+
+template <int D>
+__device__ __forceinline__ void rescale_o(f32x16 (&o)[Geom<D>::kDvBlocks], float alpha) {
+#pragma unroll
+  for (int b = 0; b < Geom<D>::kDvBlocks; ++b) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
   }
 }
 
@@ -238,6 +260,14 @@ __device__ __forceinline__ void tile_compute(lds_char* kt, lds_char* vt,
 // T: element type of Q/K/V/O in HBM (f16 or float; float is rounded to f16 while staging).
 // FAST: T == f16 and d % 8 == 0: 128-bit Q loads, direct global->LDS K/V staging, 64-bit O stores.
 //       Otherwise everything goes through range-checked element loads/stores.
+//
+// LDS: a ring of two K tiles followed by a ring of two V tiles (64 rows each).  Block schedule for
+// tile t (blocks 2t and 2t+1), with S and P double-buffered in registers as (sA, pA) / (sB, pB):
+//   step 2t   : PV(2t-1) [V tile t-1, rows 32..63]  |  S(2t+1) [K tile t, rows 32..63]  |  softmax(2t)
+//               wait for outstanding staging, barrier; stage K tile t+2 -> slot t%2 (K tile t is
+//               now fully consumed) and V tile t+1 -> slot (t+1)%2 (V tile t-1 fully consumed)
+//   step 2t+1 : PV(2t) [V tile t, rows 0..31]       |  S(2t+2) [K tile t+1, rows 0..31] |  softmax(2t+1)
+// so every staged tile has a whole tile time to land and there is one barrier per tile.
 template <int D, typename T, bool FAST>
 __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
@@ -277,8 +307,11 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   const uint32_t row_bytes = (uint32_t)d * sizeof(T);
   const uint32_t tile_step = (uint32_t)kBc * row_bytes;  // HBM bytes between consecutive K/V tiles
 
+  lds_char* const k_ring = smem;
+  lds_char* const v_ring = smem + 2 * G::kTileBytes;
+
   // ---- K/V staging --------------------------------------------------------------------------
-  // FAST: each wave issues kPiecesPerWave 1-KiB pieces per tensor; lane i of piece pc fills LDS
+  // FAST: each wave issues kPiecesPerWave 1-KiB pieces per tile; lane i of piece pc fills LDS
   // chunk pc*64 + i, i.e. row (pc*64+i)/kChunks, slot (pc*64+i)%kChunks, with the source chunk that
   // the swizzle maps there.
   uint32_t dma_off[G::kPiecesPerWave];
@@ -291,16 +324,13 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
       dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
     }
   }
-  auto stage = [&](int t, int buf) {
-    lds_char* const kdst = smem + buf * G::kStageBytes;
-    lds_char* const vdst = kdst + G::kTileBytes;
+  auto stage = [&](const __amdgpu_buffer_rsrc_t rs, int t, lds_char* dst) {
     const uint32_t toff = (uint32_t)t * tile_step;
     if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < G::kPiecesPerWave; ++i) {
         const int pc = wave * G::kPiecesPerWave + i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rs, kdst + pc * 1024, 16, dma_off[i] + toff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rs, vdst + pc * 1024, 16, dma_off[i] + toff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + pc * 1024, 16, dma_off[i] + toff, 0, 0, 0);
       }
     } else {
       // two adjacent columns per step, converted to fp16 and written as one dword
@@ -313,20 +343,26 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
         const uint32_t base = toff + (uint32_t)row * row_bytes;
         const uint32_t o0 = (col < d) ? base + (uint32_t)col * sizeof(T) : kOob;
         const uint32_t o1 = (col + 1 < d) ? base + (uint32_t)(col + 1) * sizeof(T) : kOob;
-        f16x2 kk, vv;
-        kk[0] = load_elem<T>(k_rs, o0);
-        kk[1] = load_elem<T>(k_rs, o1);
-        vv[0] = load_elem<T>(v_rs, o0);
-        vv[1] = load_elem<T>(v_rs, o1);
-        const int off = lds_off<D>(row, cp >> 2) + (cp & 3) * 4;
-        *FLASH_LDS_CAST(f16x2, kdst + off) = kk;
-        *FLASH_LDS_CAST(f16x2, vdst + off) = vv;
+        f16x2 x;
+        x[0] = load_elem<T>(rs, o0);
+        x[1] = load_elem<T>(rs, o1);
+        *FLASH_LDS_CAST(f16x2, dst + lds_off<D>(row, cp >> 2) + (cp & 3) * 4) = x;
       }
     }
   };
+  auto stage_k = [&](int t) { stage(k_rs, t, k_ring + (t & 1) * G::kTileBytes); };
+  auto stage_v = [&](int t) { stage(v_rs, t, v_ring + (t & 1) * G::kTileBytes); };
+  auto staged_barrier = [&]() {
+    // every wave waits for its own staging traffic, then all waves meet: tiles issued before this
+    // point are readable by everyone, tiles read before this point may be overwritten
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
 
   const int nt = (N + kBc - 1) / kBc;
-  stage(0, 0);
+  stage_k(0);
+  stage_v(0);
+  if (nt > 1) stage_k(1);
 
   // ---- Q fragments: B operand of S^T = K Q^T: lane (r, h) holds Q[row r][16*ks + 8*h + 0..7] ----
   const int qrow = (int)qt * kBr + wave * kRowsPerWave + r;
@@ -354,29 +390,41 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
   }
-  float m = -3.0e38f;  // running max of raw scores (finite, so the first rescale is exp2(-huge) = 0)
-  float l = 0.f;
+  SoftmaxState st;
+  st.m = -3.0e38f;  // finite, so that the first rescale factor is exp2(-huge) = 0, never NaN
+  st.l = 0.f;
+  st.alpha = 1.f;
   const float c = p.scale_log2e;
+  const bool ragged = (N % kBc) != 0;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  staged_barrier();
+
+  f32x16 sA, sB;
+  f16x8 pA[2], pB[2];
+  sA = qk_block<D>(k_ring, 0, qf, lane);  // S(0)
 
   for (int t = 0; t < nt; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nt) stage(t + 1, cur ^ 1);
-    lds_char* const kt = smem + cur * G::kStageBytes;
-    lds_char* const vt = kt + G::kTileBytes;
-    if (t == nt - 1 && (N % kBc) != 0) {
-      tile_compute<D, true>(kt, vt, qf, o, m, l, c, t * kBc, N, lane);
-    } else {
-      tile_compute<D, false>(kt, vt, qf, o, m, l, c, t * kBc, N, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    lds_char* const k_cur = k_ring + (t & 1) * G::kTileBytes;
+    lds_char* const k_nxt = k_ring + ((t + 1) & 1) * G::kTileBytes;
+    lds_char* const v_cur = v_ring + (t & 1) * G::kTileBytes;
+    lds_char* const v_prv = v_ring + ((t + 1) & 1) * G::kTileBytes;
+    const bool masked = ragged && t == nt - 1;
+    // step 2t
+    if (t > 0) pv_block<D>(v_prv, 32, pB, o, lane);
+    sB = qk_block<D>(k_cur, 32, qf, lane);
+    if (softmax_block<D>(sA, pA, st, c, t * kBc, N, masked, lane)) rescale_o<D>(o, st.alpha);
+    staged_barrier();
+    if (t + 2 < nt) stage_k(t + 2);
+    if (t + 1 < nt) stage_v(t + 1);
+    // step 2t+1
+    pv_block<D>(v_cur, 0, pA, o, lane);
+    if (t + 1 < nt) sA = qk_block<D>(k_nxt, 0, qf, lane);
+    if (softmax_block<D>(sB, pB, st, c, t * kBc + 32, N, masked, lane)) rescale_o<D>(o, st.alpha);
   }
+  pv_block<D>(v_ring + ((nt - 1) & 1) * G::kTileBytes, 32, pB, o, lane);
 
   // ---- epilogue: O = O^T / l, registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 ----------
-  const HalfPair lp = both_halves(l);
+  const HalfPair lp = both_halves(st.l);
   const float inv = 1.0f / (lp.lo + lp.hi);
 #pragma unroll
   for (int b = 0; b < G::kDvBlocks; ++b) {
