@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace flash_hip {
 
 typedef _Float16 f16;
@@ -133,61 +135,117 @@ __device__ __forceinline__ void store_elem(__amdgpu_buffer_rsrc_t rs, uint32_t b
 
 // ---- building blocks of the software pipeline -------------------------------------------------------
 // The unit of work is a BLOCK of 32 keys (half an LDS tile):
-//   qk_block       S^T(32 keys x 32 queries) = K_blk * Q^T            D/16 MFMAs
-//   softmax_block  running max, P^T = exp2(S^T*c - m*c) as fp16 B fragments, row-sum   (VALU only)
-//   pv_block       O^T += V_blk^T * P^T                                D/16 MFMAs
-// The kernel issues pv_block(j-1), qk_block(j+1) and softmax_block(j) of three consecutive blocks
-// next to each other; they are independent, so the matrix pipe and the vector ALU overlap.
+//   QK       S^T(32 keys x 32 queries) = K_blk * Q^T            D/16 MFMAs, A operand by ds_read_b128
+//   softmax  running max, P^T = exp2(S^T*c - m*c) as fp16 B fragments, row sum      (VALU only)
+//   PV       O^T += V_blk^T * P^T                                D/16 MFMAs, A operand by ds_read_b64_tr_b16
+// One STEP of the kernel runs PV(j-1) and QK(j+1) (the "matrix section") and softmax(j) (the
+// "vector section") of three consecutive blocks; the two sections are independent of each other.
 
-// S^T for the 32 keys that start at row `row0` of the K tile at `kt`.
-// Lane (r, h) reads K[row0 + r][16*ks + 8*h .. +8) as the A fragment of k-step ks.
+// Per-lane byte offsets into a K or V tile (for key row 0 of a block; blocks and k-steps add
+// multiples of 16 rows, which the swizzle does not see, so they become instruction immediates).
 template <int D>
-__device__ __forceinline__ f32x16 qk_block(lds_char* kt, int row0, const f16x8 (&qf)[Geom<D>::kKSteps], int lane) {
+struct LaneAddr {
+  int k[Geom<D>::kKSteps];        // K[r][16*ks + 8*h ..]: A fragment of k-step ks of S^T = K Q^T
+  int v[2][Geom<D>::kDvBlocks];   // V rows 8*jj + 4*h + (0..3), dv block b: half jj of an A fragment of O^T = V^T P^T
+};
+
+template <int D>
+__device__ __forceinline__ LaneAddr<D> make_lane_addr(int lane) {
   using G = Geom<D>;
+  LaneAddr<D> la;
   const int r = lane & 31;
-  const int h = lane >> 5;
-  f32x16 s;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = 0.f;
-  f16x8 a[G::kKSteps];
-#pragma unroll
-  for (int ks = 0; ks < G::kKSteps; ++ks) a[ks] = *(FLASH_LDS_CAST(f16x8, kt + lds_off<D>(row0 + r, 2 * ks + h)));
-#pragma unroll
-  for (int ks = 0; ks < G::kKSteps; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], qf[ks], s, 0, 0, 0);
-  return s;
-}
-
-// O^T[dv][q] += sum_kv V[kv][dv] * P[q][kv] for the 32 keys at rows row0.. of the V tile at `vt`.
-// A operand = V^T through transposed LDS reads: element j of half-wave h of k-step ks is key
-// 16*ks + 8*(j>>2) + 4*h + (j&3), which is the order the registers of P^T already have.
-template <int D>
-__device__ __forceinline__ void pv_block(lds_char* vt, int row0, const f16x8 (&pf)[2],
-                                         f32x16 (&o)[Geom<D>::kDvBlocks], int lane) {
-  using G = Geom<D>;
   const int h = lane >> 5;
   const int i16 = lane & 15;
   const int tq = i16 >> 2;         // row of the 4x16 transposed block this lane addresses
   const int tp = i16 & 3;          // 4-column group of that row
   const int tg = (lane >> 4) & 1;  // which 16 of the 32 dv columns
 #pragma unroll
-  for (int b = 0; b < G::kDvBlocks; ++b) {
-    f16x8 a[2];
+  for (int ks = 0; ks < G::kKSteps; ++ks) la.k[ks] = lds_off<D>(r, 2 * ks + h);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+  for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int row = row0 + 16 * ks + 8 * jj + 4 * h + tq;
-        const int off = lds_off<D>(row, b * 4 + tg * 2 + (tp >> 1)) + 8 * (tp & 1);
-        const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(FLASH_LDS_CAST(fp16x4_b, vt + off));
-        const f16x4 tv = __builtin_bit_cast(f16x4, t);
-        a[ks][4 * jj + 0] = tv[0];
-        a[ks][4 * jj + 1] = tv[1];
-        a[ks][4 * jj + 2] = tv[2];
-        a[ks][4 * jj + 3] = tv[3];
+    for (int b = 0; b < G::kDvBlocks; ++b)
+      la.v[jj][b] = lds_off<D>(8 * jj + 4 * h + tq, b * 4 + tg * 2 + (tp >> 1)) + 8 * (tp & 1);
+  }
+  return la;
+}
+
+// A fragment of O^T = V^T P^T for dv block b, k-step ks (keys 16*ks.. of the block at `vb`): element j
+// of half-wave h is key 16*ks + 8*(j>>2) + 4*h + (j&3), the order the registers of P^T already have.
+template <int D>
+__device__ __forceinline__ f16x8 read_v_frag(lds_char* vb, const LaneAddr<D>& la, int b, int ks) {
+  f16x8 a;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+        FLASH_LDS_CAST(fp16x4_b, vb + 16 * ks * Geom<D>::kRowBytes + la.v[jj][b]));
+    const f16x4 tv = __builtin_bit_cast(f16x4, t);
+    a[4 * jj + 0] = tv[0];
+    a[4 * jj + 1] = tv[1];
+    a[4 * jj + 2] = tv[2];
+    a[4 * jj + 3] = tv[3];
+  }
+  return a;
+}
+
+template <int D>
+__device__ __forceinline__ f16x8 read_k_frag(lds_char* kb, const LaneAddr<D>& la, int ks) {
+  return *(FLASH_LDS_CAST(f16x8, kb + la.k[ks]));
+}
+
+// Matrix section of one step.
+//   HAS_PV: O^T += V^T P^T for the 32 keys whose V rows start at `vb`, probabilities `pf`
+//   HAS_QK: s_out = K Q^T for the 32 keys whose K rows start at `kb`
+// LDS reads are issued ahead of the MFMAs that consume them: all K fragments and the V fragments
+// of the first two dv blocks up front, the V fragments of the next two dv blocks as soon as the
+// registers of the previous pair are free, with the QK MFMAs in between to cover their latency.
+template <int D, bool HAS_PV, bool HAS_QK>
+__device__ __forceinline__ void matrix_section(lds_char* vb, const f16x8 (&pf)[2], f32x16 (&o)[Geom<D>::kDvBlocks],
+                                               lds_char* kb, const f16x8 (&qf)[Geom<D>::kKSteps], f32x16& s_out,
+                                               const LaneAddr<D>& la) {
+  using G = Geom<D>;
+  constexpr int KS = G::kKSteps;
+  constexpr int NB = G::kDvBlocks;
+  f16x8 va[4];
+  f16x8 ka[KS];
+  if constexpr (HAS_PV) {
+    va[0] = read_v_frag<D>(vb, la, 0, 0);
+    va[1] = read_v_frag<D>(vb, la, 0, 1);
+    va[2] = read_v_frag<D>(vb, la, 1, 0);
+    va[3] = read_v_frag<D>(vb, la, 1, 1);
+  }
+  if constexpr (HAS_QK) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) ka[ks] = read_k_frag<D>(kb, la, ks);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s_out[i] = 0.f;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int b0 = 0; b0 < NB; b0 += 2) {
+    if constexpr (HAS_PV) {
+      o[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[0], pf[0], o[b0], 0, 0, 0);
+      o[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[1], pf[1], o[b0], 0, 0, 0);
+      if (b0 + 2 < NB) {
+        va[0] = read_v_frag<D>(vb, la, b0 + 2, 0);
+        va[1] = read_v_frag<D>(vb, la, b0 + 2, 1);
+      }
+      o[b0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[2], pf[0], o[b0 + 1], 0, 0, 0);
+      o[b0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[3], pf[1], o[b0 + 1], 0, 0, 0);
+      if (b0 + 2 < NB) {
+        va[2] = read_v_frag<D>(vb, la, b0 + 3, 0);
+        va[3] = read_v_frag<D>(vb, la, b0 + 3, 1);
       }
     }
+    if constexpr (HAS_QK) {
+      // half of the QK chain per dv-block pair (all of it when there is only one pair)
+      constexpr int per = (NB > 2) ? KS / 2 : KS;
+      const int k0 = (b0 / 2) * per;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], pf[ks], o[b], 0, 0, 0);
+      for (int ks = 0; ks < per; ++ks)
+        s_out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[k0 + ks], qf[k0 + ks], s_out, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -399,29 +457,77 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
 
   staged_barrier();
 
+  const LaneAddr<D> la = make_lane_addr<D>(lane);
   f32x16 sA, sB;
   f16x8 pA[2], pB[2];
-  sA = qk_block<D>(k_ring, 0, qf, lane);  // S(0)
+  constexpr int kBlk = 32 * G::kRowBytes;  // bytes of one 32-key block inside a tile
 
-  for (int t = 0; t < nt; ++t) {
-    lds_char* const k_cur = k_ring + (t & 1) * G::kTileBytes;
-    lds_char* const k_nxt = k_ring + ((t + 1) & 1) * G::kTileBytes;
-    lds_char* const v_cur = v_ring + (t & 1) * G::kTileBytes;
-    lds_char* const v_prv = v_ring + ((t + 1) & 1) * G::kTileBytes;
-    const bool masked = ragged && t == nt - 1;
-    // step 2t
-    if (t > 0) pv_block<D>(v_prv, 32, pB, o, lane);
-    sB = qk_block<D>(k_cur, 32, qf, lane);
-    if (softmax_block<D>(sA, pA, st, c, t * kBc, N, masked, lane)) rescale_o<D>(o, st.alpha);
+  // S(0)
+  matrix_section<D, false, true>(nullptr, pA, o, k_ring, qf, sA, la);
+
+  // One tile = two steps.  VF (wave-uniform): run the vector section before the matrix section.
+  // The two waves that share a SIMD (wave w and w + 4) use opposite orders, so that one of them
+  // feeds the matrix pipe while the other one runs its softmax.
+  auto tile_steps = [&](auto vf_tag, auto first_tag, auto last_tag, int t, int slot) {
+    constexpr bool VF = decltype(vf_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;  // t == 0: there is no previous block to multiply
+    constexpr bool LAST = decltype(last_tag)::value;    // t == nt-1: there is no next tile to score
+    lds_char* const k_cur = k_ring + slot * G::kTileBytes;
+    lds_char* const k_nxt = k_ring + (slot ^ 1) * G::kTileBytes;
+    lds_char* const v_cur = v_ring + slot * G::kTileBytes;
+    lds_char* const v_prv = v_ring + (slot ^ 1) * G::kTileBytes;
+    const bool masked = LAST && ragged;
+    bool rs;
+    // step 2t: PV(2t-1) | QK(2t+1) | softmax(2t)
+    if constexpr (VF) {
+      rs = softmax_block<D>(sA, pA, st, c, t * kBc, N, masked, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      matrix_section<D, !FIRST, true>(v_prv + kBlk, pB, o, k_cur + kBlk, qf, sB, la);
+    } else {
+      matrix_section<D, !FIRST, true>(v_prv + kBlk, pB, o, k_cur + kBlk, qf, sB, la);
+      rs = softmax_block<D>(sA, pA, st, c, t * kBc, N, masked, lane);
+    }
+    if (rs) rescale_o<D>(o, st.alpha);
     staged_barrier();
     if (t + 2 < nt) stage_k(t + 2);
     if (t + 1 < nt) stage_v(t + 1);
-    // step 2t+1
-    pv_block<D>(v_cur, 0, pA, o, lane);
-    if (t + 1 < nt) sA = qk_block<D>(k_nxt, 0, qf, lane);
-    if (softmax_block<D>(sB, pB, st, c, t * kBc + 32, N, masked, lane)) rescale_o<D>(o, st.alpha);
+    // step 2t+1: PV(2t) | QK(2t+2) | softmax(2t+1)
+    if constexpr (VF) {
+      rs = softmax_block<D>(sB, pB, st, c, t * kBc + 32, N, masked, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      matrix_section<D, true, !LAST>(v_cur, pA, o, k_nxt, qf, sA, la);
+    } else {
+      matrix_section<D, true, !LAST>(v_cur, pA, o, k_nxt, qf, sA, la);
+      rs = softmax_block<D>(sB, pB, st, c, t * kBc + 32, N, masked, lane);
+    }
+    if (rs) rescale_o<D>(o, st.alpha);
+  };
+  auto sweep = [&](auto vf_tag) {
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+    if (nt == 1) {
+      tile_steps(vf_tag, yes, yes, 0, 0);
+    } else {
+      tile_steps(vf_tag, yes, no, 0, 0);
+      int t = 1;
+      for (; t + 2 < nt; t += 2) {  // slots alternate 1, 0: constant LDS offsets inside the loop
+        tile_steps(vf_tag, no, no, t, 1);
+        tile_steps(vf_tag, no, no, t + 1, 0);
+      }
+      if (t + 1 < nt) {
+        tile_steps(vf_tag, no, no, t, 1);
+        ++t;
+      }
+      tile_steps(vf_tag, no, yes, t, t & 1);
+    }
+  };
+  if (wave >= kWaves / 2) {
+    sweep(std::true_type{});
+  } else {
+    sweep(std::false_type{});
   }
-  pv_block<D>(v_ring + ((nt - 1) & 1) * G::kTileBytes, 32, pB, o, lane);
+  // PV of the last block
+  matrix_section<D, true, false>(v_ring + ((nt - 1) & 1) * G::kTileBytes + kBlk, pB, o, nullptr, qf, sA, la);
 
   // ---- epilogue: O = O^T / l, registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 ----------
   const HalfPair lp = both_halves(st.l);
