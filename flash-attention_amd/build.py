@@ -50,7 +50,7 @@ def build_hip_library(force=False):
     srcs = glob.glob(os.path.join(HERE, "csrc", "*")) + [os.path.join(ROOT, "include", "flash_hip.h")]
     if force or _stale(out, srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-honor-nans", "-fPIC", "-shared",
               os.path.join(HERE, "csrc", "flash_hip.hip"), "-o", out])
     return out
 

@@ -110,6 +110,34 @@ __device__ __forceinline__ HalfPair both_halves(float x) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Raw buffer descriptor (stride 0, range-checked against `bytes`) as four wave-uniform dwords.
+typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  srd_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+
+// One direct global->LDS piece: every lane moves 16 bytes from byte offset `voff` of the buffer to
+// LDS address lds_base + 16*lane (1 KiB per wave-instruction).  Issued from inline asm on purpose:
+// the compiler does not see the load, so it neither waits for it before unrelated ds_reads nor
+// drains it at the next barrier; the kernel waits with its own s_waitcnt vmcnt(0) before the
+// barrier that publishes the tile.  M0 (the LDS base of the transfer) is written and consumed
+// inside the one statement.
+__device__ __forceinline__ void dma_piece(srd_t srd, uint32_t voff, uint32_t lds_base) {
+  asm volatile(
+      "s_mov_b32 m0, %0\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %1, %2, 0 offen lds"
+      :
+      : "s"(lds_base), "v"(voff), "s"(srd)
+      : "memory");
+}
+
 __device__ __forceinline__ f16 to_f16(f16 x) { return x; }
 __device__ __forceinline__ f16 to_f16(float x) { return (f16)x; }
 
@@ -206,8 +234,9 @@ __device__ __forceinline__ void matrix_section(lds_char* vb, const f16x8 (&pf)[2
   using G = Geom<D>;
   constexpr int KS = G::kKSteps;
   constexpr int NB = G::kDvBlocks;
+  constexpr int KH = (NB > 2) ? KS / 2 : KS;  // K fragments held at a time
   f16x8 va[4];
-  f16x8 ka[KS];
+  f16x8 ka[KH];
   if constexpr (HAS_PV) {
     va[0] = read_v_frag<D>(vb, la, 0, 0);
     va[1] = read_v_frag<D>(vb, la, 0, 1);
@@ -216,7 +245,7 @@ __device__ __forceinline__ void matrix_section(lds_char* vb, const f16x8 (&pf)[2
   }
   if constexpr (HAS_QK) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) ka[ks] = read_k_frag<D>(kb, la, ks);
+    for (int ks = 0; ks < KH; ++ks) ka[ks] = read_k_frag<D>(kb, la, ks);
 #pragma unroll
     for (int i = 0; i < 16; ++i) s_out[i] = 0.f;
   }
@@ -238,12 +267,14 @@ __device__ __forceinline__ void matrix_section(lds_char* vb, const f16x8 (&pf)[2
       }
     }
     if constexpr (HAS_QK) {
-      // half of the QK chain per dv-block pair (all of it when there is only one pair)
-      constexpr int per = (NB > 2) ? KS / 2 : KS;
-      const int k0 = (b0 / 2) * per;
+      // KH steps of the QK chain per dv-block pair; each K fragment register is refilled with the
+      // fragment KH steps later as soon as its MFMA has issued
+      const int k0 = (b0 / 2) * KH;
 #pragma unroll
-      for (int ks = 0; ks < per; ++ks)
-        s_out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[k0 + ks], qf[k0 + ks], s_out, 0, 0, 0);
+      for (int ks = 0; ks < KH; ++ks) {
+        s_out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[k0 + ks], s_out, 0, 0, 0);
+        if (k0 + KH + ks < KS) ka[ks] = read_k_frag<D>(kb, la, k0 + KH + ks);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -362,6 +393,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vh, 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
 
+  const srd_t k_srd = make_srd(kh, head_bytes);
+  const srd_t v_srd = make_srd(vh, head_bytes);
+
   const uint32_t row_bytes = (uint32_t)d * sizeof(T);
   const uint32_t tile_step = (uint32_t)kBc * row_bytes;  // HBM bytes between consecutive K/V tiles
 
@@ -382,13 +416,14 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
       dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
     }
   }
-  auto stage = [&](const __amdgpu_buffer_rsrc_t rs, int t, lds_char* dst) {
+  auto stage = [&](const __amdgpu_buffer_rsrc_t rs, const srd_t srd, int t, lds_char* dst) __attribute__((always_inline)) {
     const uint32_t toff = (uint32_t)t * tile_step;
     if constexpr (FAST) {
 #pragma unroll
       for (int i = 0; i < G::kPiecesPerWave; ++i) {
         const int pc = wave * G::kPiecesPerWave + i;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst + pc * 1024, 16, dma_off[i] + toff, 0, 0, 0);
+        const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(dst + pc * 1024));
+        dma_piece(srd, dma_off[i] + toff, lds_base);
       }
     } else {
       // two adjacent columns per step, converted to fp16 and written as one dword
@@ -408,9 +443,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
       }
     }
   };
-  auto stage_k = [&](int t) { stage(k_rs, t, k_ring + (t & 1) * G::kTileBytes); };
-  auto stage_v = [&](int t) { stage(v_rs, t, v_ring + (t & 1) * G::kTileBytes); };
-  auto staged_barrier = [&]() {
+  auto stage_k = [&](int t) __attribute__((always_inline)) { stage(k_rs, k_srd, t, k_ring + (t & 1) * G::kTileBytes); };
+  auto stage_v = [&](int t) __attribute__((always_inline)) { stage(v_rs, v_srd, t, v_ring + (t & 1) * G::kTileBytes); };
+  auto staged_barrier = [&]() __attribute__((always_inline)) {
     // every wave waits for its own staging traffic, then all waves meet: tiles issued before this
     // point are readable by everyone, tiles read before this point may be overwritten
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -468,7 +503,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   // One tile = two steps.  VF (wave-uniform): run the vector section before the matrix section.
   // The two waves that share a SIMD (wave w and w + 4) use opposite orders, so that one of them
   // feeds the matrix pipe while the other one runs its softmax.
-  auto tile_steps = [&](auto vf_tag, auto first_tag, auto last_tag, int t, int slot) {
+  auto tile_steps = [&](auto vf_tag, auto first_tag, auto last_tag, int t, int slot) __attribute__((always_inline)) {
     constexpr bool VF = decltype(vf_tag)::value;
     constexpr bool FIRST = decltype(first_tag)::value;  // t == 0: there is no previous block to multiply
     constexpr bool LAST = decltype(last_tag)::value;    // t == nt-1: there is no next tile to score
@@ -502,7 +537,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
     }
     if (rs) rescale_o<D>(o, st.alpha);
   };
-  auto sweep = [&](auto vf_tag) {
+  auto sweep = [&](auto vf_tag) __attribute__((always_inline)) {
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
     if (nt == 1) {
