@@ -7,11 +7,13 @@
 // registers, streams K/V tiles through LDS and keeps the running row max / row sum in registers.
 // Nothing of the reference's structure is kept beyond that:
 //
-//   * A workgroup is 8 waves x 32 query rows = 256 rows (Br), K/V tiles are 64 rows (Bc).
+//   * A workgroup is 4 waves, ONE PER SIMD, each with the whole 512-entry register file and 64
+//     query rows (two 32-row query blocks): 256 rows per workgroup (Br).  K/V tiles are 64 rows
+//     (Bc), processed as two 32-key blocks.  Every K/V fragment read from LDS feeds two MFMAs.
 //   * Scores are produced TRANSPOSED: S^T = K * Q^T, A operand = K rows from LDS (ds_read_b128),
-//     B operand = Q held in VGPRs.  In the 32x32 accumulator layout the query index is then the
-//     lane (lane & 31) and the key index runs over the 16 registers, so the row max / row sum of
-//     the online softmax are in-lane reductions plus ONE v_permlane32_swap between the two
+//     B operand = Q held in registers.  In the 32x32 accumulator layout the query index is then
+//     the lane (lane & 31) and the key index runs over the 16 registers, so the row max / row sum
+//     of the online softmax are in-lane reductions plus ONE v_permlane32_swap between the two
 //     half-waves; no LDS round trip for S or P (the reference stores S to shared memory three
 //     times per tile, kernel_mma_qreg.cuh:166,185,200).
 //   * The output is accumulated TRANSPOSED as well: O^T = V^T * P^T.  P^T is exactly the S^T
@@ -20,10 +22,14 @@
 //     permuted key order.  The softmax rescale factor is a per-lane scalar for every register of
 //     O^T.  O stays in registers for the whole K/V sweep and is divided by the row sum once
 //     (the reference read-modify-writes O in HBM for every K/V tile, kernel_mma_qreg.cuh:207-250).
-//   * K/V tiles are double-buffered in LDS.  Staging is one of: direct global->LDS
-//     (buffer_load_dwordx4 ... lds), or through registers for head dims that are not a multiple
-//     of 8 halves and for fp32 callers.  The LDS image is XOR-swizzled at 16-byte granularity so
-//     that both the K row reads and the V transposed reads are bank-conflict free.
+//   * Software pipeline over 32-key blocks: a step issues the MFMAs of QK(j+1) and PV(j-1) and, in
+//     their shadow, the exponentials of block j and the row max of block j+1.  The rescale of O to a
+//     new row max is deferred (threshold) and happens between steps, so a step has no branches.
+//   * K/V tiles live in two 3-slot LDS rings filled by direct global->LDS loads
+//     (buffer_load_dwordx4 ... lds) one whole tile iteration ahead; head dims that are not a
+//     multiple of 8 halves and fp32 callers stage through registers instead.  The LDS image is
+//     XOR-swizzled at 16-byte granularity so that both the K row reads and the V transposed reads
+//     are bank-conflict free.
 //   * Out-of-range rows/columns are handled by the buffer descriptor's range check (loads return 0,
 //     stores are dropped); only the key-side tail needs an explicit -inf mask.
 #pragma once
@@ -45,8 +51,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 #define FLASH_LDS_CAST(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-constexpr int kWaves = 8;                   // waves per workgroup
-constexpr int kRowsPerWave = 32;            // query rows per wave (one 32x32 MFMA column block)
+constexpr int kWaves = 4;                   // waves per workgroup, one per SIMD
+constexpr int kQB = 2;                      // 32-row query blocks per wave
+constexpr int kRowsPerWave = 32 * kQB;      // 64 query rows per wave
 constexpr int kBr = kWaves * kRowsPerWave;  // 256 query rows per workgroup
 constexpr int kBc = 64;                     // key/value rows per LDS tile
 constexpr int kThreads = kWaves * 64;
@@ -72,10 +79,11 @@ struct Geom {
   static constexpr int kRowBytes = D * 2;             // LDS row of fp16
   static constexpr int kChunks = D / 8;               // 16-byte chunks per row
   static constexpr int kKSteps = D / 16;              // MFMA k-steps of S^T = K Q^T
+  static constexpr int kKHold = (D > 64) ? D / 32 : D / 16;  // K fragments held in registers at a time
   static constexpr int kDvBlocks = D / 32;            // 32-wide blocks of O^T rows
   static constexpr int kTileBytes = kBc * kRowBytes;  // one K or V tile
-  static constexpr int kStageBytes = 2 * kTileBytes;  // K + V
-  static constexpr int kLdsBytes = 2 * kStageBytes;   // double buffered
+  static constexpr int kSlots = 3;                    // tiles per LDS ring (K ring + V ring)
+  static constexpr int kLdsBytes = 2 * kSlots * kTileBytes;
   static constexpr int kPieces = kTileBytes / 1024;   // 1-KiB wave-instructions per tile
   static constexpr int kPiecesPerWave = kPieces / kWaves;
 };
@@ -99,7 +107,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * Geom<D>::kRowBytes + ((chunk ^ swz<D>(row)) << 4);
 }
 
-// x of this lane's row as held by the lower (r[0]) and the upper (r[1]) half-wave.
+// x of this lane's row as held by the lower (lo) and the upper (hi) half-wave.
 struct HalfPair {
   float lo, hi;
 };
@@ -109,6 +117,49 @@ __device__ __forceinline__ HalfPair both_halves(float x) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// MFMAs are issued from inline asm so that the register FILE of each operand is fixed: with one wave
+// per SIMD a lane owns 256 architectural VGPRs and 256 accumulation registers (AGPRs); O^T and the Q
+// fragments are only ever touched by MFMAs and live in AGPRs for the whole kernel, everything the
+// vector ALU works on (scores, probabilities, K/V fragments) lives in VGPRs.  Left to the compiler,
+// the B operand is always taken from a VGPR and the AGPRs degrade to spill space (four
+// v_accvgpr_read per MFMA).
+// The price: the compiler does not know these statements are MFMAs and pads no hazards for them.
+// The kernel keeps every consumer of an MFMA result at least two MFMAs behind its producer; where
+// that is not structurally guaranteed (prologue, rescale path, epilogue) it calls mfma_drain().
+// A register copy that the compiler places directly in front of such a statement (it does so when it
+// keeps an operand in the other register file) would be read too early: v_accvgpr_write -> MFMA
+// needs two wait states.  PAD = true prefixes them to every MFMA; the tuned kernels (PAD = false)
+// keep all operands resident in the right file instead, which tests/test_kernel_asm.py verifies on
+// the generated code.
+//   S^T accumulate:  acc (VGPR) += A (VGPR: K fragment) * B (AGPR: Q fragment)
+template <bool PAD>
+__device__ __forceinline__ void mfma_s_first(f32x16& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (PAD) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+  } else {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+  }
+}
+template <bool PAD>
+__device__ __forceinline__ void mfma_s(f32x16& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (PAD) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  } else {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  }
+}
+//   O^T accumulate:  acc (AGPR) += A (VGPR: V^T fragment) * B (VGPR: P^T fragment)
+template <bool PAD>
+__device__ __forceinline__ void mfma_o(f32x16& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (PAD) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  }
+}
+// Wait states that cover the result latency of the last MFMA before other instructions read it.
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
 // Raw buffer descriptor (stride 0, range-checked against `bytes`) as four wave-uniform dwords.
 typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
@@ -138,9 +189,6 @@ __device__ __forceinline__ void dma_piece(srd_t srd, uint32_t voff, uint32_t lds
       : "memory");
 }
 
-__device__ __forceinline__ f16 to_f16(f16 x) { return x; }
-__device__ __forceinline__ f16 to_f16(float x) { return (f16)x; }
-
 // ---- element access through a raw buffer descriptor (range-checked) --------------------------
 template <typename T>
 __device__ __forceinline__ f16 load_elem(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off);
@@ -162,23 +210,24 @@ __device__ __forceinline__ void store_elem(__amdgpu_buffer_rsrc_t rs, uint32_t b
 }
 
 // ---- building blocks of the software pipeline -------------------------------------------------------
-// The unit of work is a BLOCK of 32 keys (half an LDS tile):
+// The unit of work is a BLOCK of 32 keys (half an LDS tile), for each of the wave's query blocks:
 //   QK       S^T(32 keys x 32 queries) = K_blk * Q^T            D/16 MFMAs, A operand by ds_read_b128
 //   softmax  running max, P^T = exp2(S^T*c - m*c) as fp16 B fragments, row sum      (VALU only)
 //   PV       O^T += V_blk^T * P^T                                D/16 MFMAs, A operand by ds_read_b64_tr_b16
-// One STEP of the kernel runs PV(j-1) and QK(j+1) (the "matrix section") and softmax(j) (the
-// "vector section") of three consecutive blocks; the two sections are independent of each other.
 
-// Per-lane byte offsets into a K or V tile (for key row 0 of a block; blocks and k-steps add
-// multiples of 16 rows, which the swizzle does not see, so they become instruction immediates).
+// Per-lane LDS byte addresses of the fragment reads, for slot 0 / key row 0 of each ring.  Slots,
+// blocks and k-steps add multiples of 16 rows, which the swizzle does not see, so they are
+// compile-time constants that end up in the 16-bit offset field of the ds_read (this is why the
+// addresses are absolute and opaque to the compiler: a constant that it could fold with the ring
+// base would exceed that field and cost one address register per slot and block).
 template <int D>
 struct LaneAddr {
-  int k[Geom<D>::kKSteps];        // K[r][16*ks + 8*h ..]: A fragment of k-step ks of S^T = K Q^T
-  int v[2][Geom<D>::kDvBlocks];   // V rows 8*jj + 4*h + (0..3), dv block b: half jj of an A fragment of O^T = V^T P^T
+  uint32_t k[Geom<D>::kKSteps];       // K[r][16*ks + 8*h ..]: A fragment of k-step ks of S^T = K Q^T
+  uint32_t v[2][Geom<D>::kDvBlocks];  // V rows 8*jj + 4*h + (0..3), dv block b: half jj of an A fragment of O^T
 };
 
 template <int D>
-__device__ __forceinline__ LaneAddr<D> make_lane_addr(int lane) {
+__device__ __forceinline__ LaneAddr<D> make_lane_addr(int lane, lds_char* k_ring, lds_char* v_ring) {
   using G = Geom<D>;
   LaneAddr<D> la;
   const int r = lane & 31;
@@ -187,26 +236,36 @@ __device__ __forceinline__ LaneAddr<D> make_lane_addr(int lane) {
   const int tq = i16 >> 2;         // row of the 4x16 transposed block this lane addresses
   const int tp = i16 & 3;          // 4-column group of that row
   const int tg = (lane >> 4) & 1;  // which 16 of the 32 dv columns
+  const uint32_t kbase = (uint32_t)(uintptr_t)k_ring;
+  const uint32_t vbase = (uint32_t)(uintptr_t)v_ring;
 #pragma unroll
-  for (int ks = 0; ks < G::kKSteps; ++ks) la.k[ks] = lds_off<D>(r, 2 * ks + h);
+  for (int ks = 0; ks < G::kKSteps; ++ks) {
+    uint32_t a = kbase + (uint32_t)lds_off<D>(r, 2 * ks + h);
+    asm volatile("" : "+v"(a));
+    la.k[ks] = a;
+  }
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) {
 #pragma unroll
-    for (int b = 0; b < G::kDvBlocks; ++b)
-      la.v[jj][b] = lds_off<D>(8 * jj + 4 * h + tq, b * 4 + tg * 2 + (tp >> 1)) + 8 * (tp & 1);
+    for (int b = 0; b < G::kDvBlocks; ++b) {
+      uint32_t a = vbase + (uint32_t)(lds_off<D>(8 * jj + 4 * h + tq, b * 4 + tg * 2 + (tp >> 1)) + 8 * (tp & 1));
+      asm volatile("" : "+v"(a));
+      la.v[jj][b] = a;
+    }
   }
   return la;
 }
 
-// A fragment of O^T = V^T P^T for dv block b, k-step ks (keys 16*ks.. of the block at `vb`): element j
-// of half-wave h is key 16*ks + 8*(j>>2) + 4*h + (j&3), the order the registers of P^T already have.
+// A fragment of O^T = V^T P^T for dv block b, k-step ks of the 32-key block that starts `voff` bytes
+// into the V ring: element j of half-wave h is key 16*ks + 8*(j>>2) + 4*h + (j&3), the order the
+// registers of P^T already have.
 template <int D>
-__device__ __forceinline__ f16x8 read_v_frag(lds_char* vb, const LaneAddr<D>& la, int b, int ks) {
+__device__ __forceinline__ f16x8 read_v_frag(uint32_t voff, const LaneAddr<D>& la, int b, int ks) {
   f16x8 a;
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) {
-    const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-        FLASH_LDS_CAST(fp16x4_b, vb + 16 * ks * Geom<D>::kRowBytes + la.v[jj][b]));
+    const uint32_t addr = la.v[jj][b] + (voff + (uint32_t)(16 * ks * Geom<D>::kRowBytes));
+    const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(FLASH_LDS_CAST(fp16x4_b, (uintptr_t)addr));
     const f16x4 tv = __builtin_bit_cast(f16x4, t);
     a[4 * jj + 0] = tv[0];
     a[4 * jj + 1] = tv[1];
@@ -216,124 +275,26 @@ __device__ __forceinline__ f16x8 read_v_frag(lds_char* vb, const LaneAddr<D>& la
   return a;
 }
 
+// A fragment of S^T = K Q^T, k-step ks of the 32-key block that starts `koff` bytes into the K ring.
 template <int D>
-__device__ __forceinline__ f16x8 read_k_frag(lds_char* kb, const LaneAddr<D>& la, int ks) {
-  return *(FLASH_LDS_CAST(f16x8, kb + la.k[ks]));
+__device__ __forceinline__ f16x8 read_k_frag(uint32_t koff, const LaneAddr<D>& la, int ks) {
+  return *(FLASH_LDS_CAST(f16x8, (uintptr_t)(la.k[ks] + koff)));
 }
 
-// Matrix section of one step.
-//   HAS_PV: O^T += V^T P^T for the 32 keys whose V rows start at `vb`, probabilities `pf`
-//   HAS_QK: s_out = K Q^T for the 32 keys whose K rows start at `kb`
-// LDS reads are issued ahead of the MFMAs that consume them: all K fragments and the V fragments
-// of the first two dv blocks up front, the V fragments of the next two dv blocks as soon as the
-// registers of the previous pair are free, with the QK MFMAs in between to cover their latency.
-template <int D, bool HAS_PV, bool HAS_QK>
-__device__ __forceinline__ void matrix_section(lds_char* vb, const f16x8 (&pf)[2], f32x16 (&o)[Geom<D>::kDvBlocks],
-                                               lds_char* kb, const f16x8 (&qf)[Geom<D>::kKSteps], f32x16& s_out,
-                                               const LaneAddr<D>& la) {
-  using G = Geom<D>;
-  constexpr int KS = G::kKSteps;
-  constexpr int NB = G::kDvBlocks;
-  constexpr int KH = (NB > 2) ? KS / 2 : KS;  // K fragments held at a time
-  f16x8 va[4];
-  f16x8 ka[KH];
-  if constexpr (HAS_PV) {
-    va[0] = read_v_frag<D>(vb, la, 0, 0);
-    va[1] = read_v_frag<D>(vb, la, 0, 1);
-    va[2] = read_v_frag<D>(vb, la, 1, 0);
-    va[3] = read_v_frag<D>(vb, la, 1, 1);
-  }
-  if constexpr (HAS_QK) {
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks) ka[ks] = read_k_frag<D>(kb, la, ks);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s_out[i] = 0.f;
-  }
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int b0 = 0; b0 < NB; b0 += 2) {
-    if constexpr (HAS_PV) {
-      o[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[0], pf[0], o[b0], 0, 0, 0);
-      o[b0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[1], pf[1], o[b0], 0, 0, 0);
-      if (b0 + 2 < NB) {
-        va[0] = read_v_frag<D>(vb, la, b0 + 2, 0);
-        va[1] = read_v_frag<D>(vb, la, b0 + 2, 1);
-      }
-      o[b0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[2], pf[0], o[b0 + 1], 0, 0, 0);
-      o[b0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va[3], pf[1], o[b0 + 1], 0, 0, 0);
-      if (b0 + 2 < NB) {
-        va[2] = read_v_frag<D>(vb, la, b0 + 3, 0);
-        va[3] = read_v_frag<D>(vb, la, b0 + 3, 1);
-      }
-    }
-    if constexpr (HAS_QK) {
-      // KH steps of the QK chain per dv-block pair; each K fragment register is refilled with the
-      // fragment KH steps later as soon as its MFMA has issued
-      const int k0 = (b0 / 2) * KH;
-#pragma unroll
-      for (int ks = 0; ks < KH; ++ks) {
-        s_out = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[ks], qf[k0 + ks], s_out, 0, 0, 0);
-        if (k0 + KH + ks < KS) ka[ks] = read_k_frag<D>(kb, la, k0 + KH + ks);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Running softmax state of one lane: its query is lane & 31, its keys are those of its half-wave.
+// Running softmax state of one lane for one of its query blocks: the query is lane & 31 of that
+// block, the keys are those of the lane's half-wave.
 struct SoftmaxState {
-  float m;      // reference max of the raw scores that P and O are currently scaled against
-  float l;      // this lane's partial row sum at that scale
-  float alpha;  // pending rescale factor for O (1 if none); applied by the caller after the
-                // previous block's P V product has been accumulated
+  float m;        // reference max (raw scores) that P, l and O are scaled against
+  float mc;       // m * c
+  float l;        // this lane's partial row sum at that scale
+  float alpha;    // factor still to be applied to O (valid while the wave's `pending` flag is set)
+  float mx_next;  // row max of the next block's scores (both half-waves)
 };
 
 // How far (in exp2 units, i.e. score * scale * log2 e) the row max may run ahead of `m` before the
 // state is rescaled.  P then stays below 2^kDeferLog2 = 256, far inside fp16 range, and O / l are
 // fp32, so the result is the same up to rounding; it saves the O-wide multiply on most blocks.
 constexpr float kDeferLog2 = 8.0f;
-
-// Softmax of one S^T block (keys kv0 + (i&3) + 8*(i>>2) + 4*h for register i).  Returns P^T as the
-// two fp16 B fragments of the block.  `masked`: keys >= N are excluded (wave-uniform flag).
-// Returns true (wave-uniform) when the caller has to multiply O by st.alpha.
-template <int D>
-__device__ __forceinline__ bool softmax_block(f32x16& s, f16x8 (&pf)[2], SoftmaxState& st, float c, int kv0, int N,
-                                              bool masked, int lane) {
-  const int h = lane >> 5;
-  if (masked) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int kv = kv0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (kv >= N) s[i] = -INFINITY;
-    }
-  }
-  float mx = fmaxf(s[0], s[1]);
-#pragma unroll
-  for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s[i], s[i + 1]));
-  const HalfPair mp = both_halves(mx);
-  mx = fmaxf(mp.lo, mp.hi);
-  // wave-uniform decision: rescale only if some row's max ran ahead of its reference by more than
-  // the deferral window (always true for the first block, where m is -huge)
-  const bool need = (mx - st.m) * c > kDeferLog2;
-  const bool rescale = __builtin_amdgcn_ballot_w64(need) != 0;
-  st.alpha = 1.0f;
-  if (rescale) {
-    const float m_new = fmaxf(st.m, mx);
-    st.alpha = fast_exp2((st.m - m_new) * c);
-    st.m = m_new;
-    st.l *= st.alpha;
-  }
-  const float mc = st.m * c;
-  float rs = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float pv = fast_exp2(__builtin_fmaf(s[i], c, -mc));
-    rs += pv;
-    pf[i >> 3][i & 7] = (f16)pv;
-  }
-  st.l += rs;
-  return rescale;
-}
 
 template <int D>
 __device__ __forceinline__ void rescale_o(f32x16 (&o)[Geom<D>::kDvBlocks], float alpha) {
@@ -344,21 +305,213 @@ __device__ __forceinline__ void rescale_o(f32x16 (&o)[Geom<D>::kDvBlocks], float
   }
 }
 
+// Keys >= N get a score of -inf.  Register i of an S^T block holds key kv0 + (i&3) + 8*(i>>2) + 4*h.
+__device__ __forceinline__ void mask_scores(f32x16& s, int kv0, int N, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int kv = kv0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (kv >= N) s[i] = -INFINITY;
+  }
+}
+
+// Row max of an S^T block over both half-waves.
+__device__ __forceinline__ float block_row_max(const f32x16& s) {
+  float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+  for (int i = 2; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s[i], s[i + 1]));
+  const HalfPair mp = both_halves(mx);
+  return fmaxf(mp.lo, mp.hi);
+}
+
+// One pipeline step.  The instruction order below is the intended issue order: the step is cut into
+// SLOTS of one MFMA each, and every slot also carries the LDS reads and the few vector instructions
+// that should issue in the shadow of that MFMA (one v_exp per slot at D = 128); a scheduling fence
+// after each slot keeps the compiler from regrouping them (left alone it hoists every LDS read to
+// the top of the step and spills).
+//   QK slots (KS * kQB)    QK(j+1): s_nxt[q] += K_{j+1}[ks] * Q[q][ks]; the K fragment register just
+//                          consumed by both query blocks is refilled (rest of this block, then the
+//                          first fragments of block j+2)
+//   PV slots (2*NB * kQB)  PV(j-1): O^T[q][b] += V_{j-1}^T[b] * P_{j-1}[q]^T, V fragments two dv blocks
+//                          ahead; row max of s_nxt once the QK chain has drained
+//   all slots              exp(j): a share of p_cur = exp2(s_cur*c - m*c) and of the row sum
+template <int D, bool PAD, bool HAS_QK, bool HAS_PRELOAD, bool MASKED>
+__device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t kb_next, const LaneAddr<D>& la,
+                                              const f16x8 (&qf)[kQB][Geom<D>::kKSteps], f16x8 (&ka)[Geom<D>::kKHold],
+                                              f32x16 (&o)[kQB][Geom<D>::kDvBlocks], const f32x16 (&s_cur)[kQB],
+                                              f32x16 (&s_nxt)[kQB], const f16x8 (&p_prev)[kQB][2],
+                                              f16x8 (&p_cur)[kQB][2], SoftmaxState (&st)[kQB], float c, int kv_next0,
+                                              int N, int lane) {
+  using G = Geom<D>;
+  constexpr int KS = G::kKSteps;
+  constexpr int KH = G::kKHold;
+  constexpr int NB = G::kDvBlocks;
+  constexpr int QK_SLOTS = KS * kQB;
+  constexpr int PV_SLOTS = 2 * NB * kQB;
+  constexpr int SLOTS = QK_SLOTS + PV_SLOTS;
+  constexpr int EPS = 16 * kQB / SLOTS;  // exp elements per slot (1 for D=128, 2 for D=64)
+  static_assert(EPS * SLOTS == 16 * kQB, "exp elements must divide evenly over the slots");
+  constexpr int MAX_OPS = 5 * kQB;       // row-max micro-ops: 4 four-register chunks + 1 cross-half per block
+  constexpr int MAX_DELAY = 2;           // PV slots to wait for the QK chain to drain
+
+  f16x8 va[4];
+  float rs[kQB];
+  float nmc[kQB];
+  float mx[kQB];
+  float xprev = 0.f;
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) {
+    rs[q] = 0.f;
+    nmc[q] = -st[q].mc;
+    mx[q] = 0.f;
+  }
+
+  // exp(j) share of slot n: element g = n*EPS + e of the 16*kQB elements (query block g/16)
+  auto exp_share = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < EPS; ++e) {
+      const int g = n * EPS + e;
+      const int q = g / 16, i = g % 16;
+      const float x = fast_exp2(__builtin_fmaf(s_cur[q][i], c, nmc[q]));
+      rs[q] += x;
+      if ((i & 1) == 0) {
+        xprev = x;
+      } else {
+        f16x2 pk;
+        pk[0] = (f16)xprev;
+        pk[1] = (f16)x;
+        // pin the packed pair and the running sum to this slot: otherwise the compiler keeps the
+        // fp32 exponentials alive and converts / adds them several slots later
+        uint32_t w = __builtin_bit_cast(uint32_t, pk);
+        asm volatile("" : "+v"(w), "+v"(rs[q]));
+        pk = __builtin_bit_cast(f16x2, w);
+        p_cur[q][i >> 3][(i & 7) - 1] = pk[0];
+        p_cur[q][i >> 3][i & 7] = pk[1];
+      }
+    }
+  };
+  // row-max micro-op u (0 .. MAX_OPS-1) of s_nxt: chunk u%5 < 4 folds registers 4c..4c+3, u%5 == 4
+  // combines the two half-waves
+  auto max_op = [&](int u) __attribute__((always_inline)) {
+    const int q = u / 5, cidx = u % 5;
+    if (cidx == 0) {
+      if constexpr (MASKED) mask_scores(s_nxt[q], kv_next0, N, lane);
+      mx[q] = fmaxf(fmaxf(s_nxt[q][0], s_nxt[q][1]), fmaxf(s_nxt[q][2], s_nxt[q][3]));
+    } else if (cidx < 4) {
+      mx[q] = fmaxf(mx[q], fmaxf(fmaxf(s_nxt[q][4 * cidx], s_nxt[q][4 * cidx + 1]),
+                                 fmaxf(s_nxt[q][4 * cidx + 2], s_nxt[q][4 * cidx + 3])));
+    } else {
+      const HalfPair mp = both_halves(mx[q]);
+      st[q].mx_next = fmaxf(mp.lo, mp.hi);
+    }
+  };
+
+  // ---- QK slots ------------------------------------------------------------------------------------
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int q = 0; q < kQB; ++q) {
+      const int n = ks * kQB + q;
+      if constexpr (HAS_QK) {
+        if (ks == 0) {
+          mfma_s_first<PAD>(s_nxt[q], ka[ks % KH], qf[q][ks]);
+        } else {
+          mfma_s<PAD>(s_nxt[q], ka[ks % KH], qf[q][ks]);
+        }
+        if (q == kQB - 1) {
+          if (ks + KH < KS) {
+            ka[ks % KH] = read_k_frag<D>(kb, la, ks + KH);
+          } else if constexpr (HAS_PRELOAD) {
+            ka[ks % KH] = read_k_frag<D>(kb_next, la, ks + KH - KS);
+          }
+        }
+      }
+      // V fragments of the first two dv blocks, a few slots before the PV slots begin
+      if (n == QK_SLOTS - 6 || (QK_SLOTS < 6 && n == 0)) {
+        va[0] = read_v_frag<D>(vb, la, 0, 0);
+        va[1] = read_v_frag<D>(vb, la, 0, 1);
+      }
+      if (n == QK_SLOTS - 4 || (QK_SLOTS < 6 && n == 1)) {
+        va[2] = read_v_frag<D>(vb, la, 1, 0);
+        va[3] = read_v_frag<D>(vb, la, 1, 1);
+      }
+      exp_share(n);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- PV slots ------------------------------------------------------------------------------------
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) {
+        const int pslot = (b * 2 + ks) * kQB + q;
+        const int vi = (b & 1) * 2 + ks;
+        mfma_o<PAD>(o[q][b], va[vi], p_prev[q][ks]);
+        if (q == kQB - 1 && b + 2 < NB) va[vi] = read_v_frag<D>(vb, la, b + 2, ks);
+        exp_share(QK_SLOTS + pslot);
+        if constexpr (HAS_QK) {
+#pragma unroll
+          for (int u = 0; u < MAX_OPS; ++u) {
+            if (MAX_DELAY + u * (PV_SLOTS - MAX_DELAY) / MAX_OPS == pslot) max_op(u);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) st[q].l += rs[q];
+}
+
+// Between two steps: apply a pending O rescale (the P V product it had to wait for has been issued),
+// then decide whether the block whose row max is st.mx_next forces a new reference max.  Both are
+// rare, wave-uniform events; the common path is one scalar test.
+template <int D>
+__device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], SoftmaxState (&st)[kQB], bool& pending,
+                                         float c, bool has_next) {
+  bool need = false;
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) need = need || ((st[q].mx_next - st[q].m) * c > kDeferLog2);
+  const bool any_need = has_next && (__builtin_amdgcn_ballot_w64(need) != 0);
+  if (pending || any_need) {
+    if (pending) {
+      mfma_drain();  // the last P V MFMAs of the step must have written O
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) rescale_o<D>(o[q], st[q].alpha);
+    }
+    pending = false;
+    if (any_need) {
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) {
+        const float m_new = fmaxf(st[q].m, st[q].mx_next);
+        st[q].alpha = fast_exp2((st[q].m - m_new) * c);  // 1 for rows whose reference does not move
+        st[q].m = m_new;
+        st[q].mc = m_new * c;
+        st[q].l *= st[q].alpha;
+      }
+      pending = true;
+    }
+  }
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------
 // D: compiled head-dim tile (d <= D, missing columns are zero-filled).
 // T: element type of Q/K/V/O in HBM (f16 or float; float is rounded to f16 while staging).
 // FAST: T == f16 and d % 8 == 0: 128-bit Q loads, direct global->LDS K/V staging, 64-bit O stores.
 //       Otherwise everything goes through range-checked element loads/stores.
 //
-// LDS: a ring of two K tiles followed by a ring of two V tiles (64 rows each).  Block schedule for
-// tile t (blocks 2t and 2t+1), with S and P double-buffered in registers as (sA, pA) / (sB, pB):
-//   step 2t   : PV(2t-1) [V tile t-1, rows 32..63]  |  S(2t+1) [K tile t, rows 32..63]  |  softmax(2t)
-//               wait for outstanding staging, barrier; stage K tile t+2 -> slot t%2 (K tile t is
-//               now fully consumed) and V tile t+1 -> slot (t+1)%2 (V tile t-1 fully consumed)
-//   step 2t+1 : PV(2t) [V tile t, rows 0..31]       |  S(2t+2) [K tile t+1, rows 0..31] |  softmax(2t+1)
-// so every staged tile has a whole tile time to land and there is one barrier per tile.
+// LDS: a ring of three K tiles followed by a ring of three V tiles (64 rows = two blocks each).
+// Tile iteration t runs
+//   step 2t   : QK(2t+1) [K tile t, rows 32..63]  PV(2t-1) [V tile t-1, rows 32..63]  exp(2t)   max(2t+1)
+//   step 2t+1 : QK(2t+2) [K tile t+1, rows 0..31] PV(2t)   [V tile t, rows 0..31]     exp(2t+1) max(2t+2)
+// and touches K tiles t, t+1 and V tiles t-1, t.  At its start it stages K tile t+2 and V tile t+1
+// into the slots of K tile t-1 and V tile t-2; at its end every wave waits for its own staging
+// traffic and all waves meet at the one barrier of the iteration.  A staged tile therefore has a
+// whole iteration to land, and nothing that a barrier publishes is needed right after that barrier.
 template <int D, typename T, bool FAST>
-__global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub
   using G = Geom<D>;
   static_assert(!FAST || sizeof(T) == 2, "direct-to-LDS staging needs fp16 data in HBM");
@@ -369,9 +522,9 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   // contiguous ranges (workgroup ids that are equal mod 8 share an XCD and hence an L2), so the
   // workgroups that stream the same K/V run on the same L2 at about the same time.
   const uint32_t bid = blockIdx.x;
-  const uint32_t xcd = bid & 7u, slot = bid >> 3;
+  const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
   const uint32_t per = p.total_wg >> 3, rem = p.total_wg & 7u;
-  const uint32_t item = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot;
+  const uint32_t item = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot_id;
   const uint32_t head = item / (uint32_t)p.nqt;
   const uint32_t qt = item - head * (uint32_t)p.nqt;
 
@@ -392,7 +545,6 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kh, 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vh, 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
-
   const srd_t k_srd = make_srd(kh, head_bytes);
   const srd_t v_srd = make_srd(vh, head_bytes);
 
@@ -400,7 +552,7 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   const uint32_t tile_step = (uint32_t)kBc * row_bytes;  // HBM bytes between consecutive K/V tiles
 
   lds_char* const k_ring = smem;
-  lds_char* const v_ring = smem + 2 * G::kTileBytes;
+  lds_char* const v_ring = smem + G::kSlots * G::kTileBytes;
 
   // ---- K/V staging --------------------------------------------------------------------------
   // FAST: each wave issues kPiecesPerWave 1-KiB pieces per tile; lane i of piece pc fills LDS
@@ -443,8 +595,8 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
       }
     }
   };
-  auto stage_k = [&](int t) __attribute__((always_inline)) { stage(k_rs, k_srd, t, k_ring + (t & 1) * G::kTileBytes); };
-  auto stage_v = [&](int t) __attribute__((always_inline)) { stage(v_rs, v_srd, t, v_ring + (t & 1) * G::kTileBytes); };
+  auto stage_k = [&](int t, int slot) __attribute__((always_inline)) { stage(k_rs, k_srd, t, k_ring + slot * G::kTileBytes); };
+  auto stage_v = [&](int t, int slot) __attribute__((always_inline)) { stage(v_rs, v_srd, t, v_ring + slot * G::kTileBytes); };
   auto staged_barrier = [&]() __attribute__((always_inline)) {
     // every wave waits for its own staging traffic, then all waves meet: tiles issued before this
     // point are readable by everyone, tiles read before this point may be overwritten
@@ -453,137 +605,178 @@ __global__ __launch_bounds__(kThreads, 2) void attn_fwd_kernel(const FwdParams p
   };
 
   const int nt = (N + kBc - 1) / kBc;
-  stage_k(0);
-  stage_v(0);
-  if (nt > 1) stage_k(1);
+  constexpr int kBlk = 32 * G::kRowBytes;  // bytes of one 32-key block inside a tile
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (nt > 1) stage_k(1, 1);
+  // Step 0 multiplies P(-1) = 0 with the second block of "V tile -1" (slot 2): make that finite.
+  for (int i = tid * 16; i < kBlk; i += kThreads * 16) {
+    *FLASH_LDS_CAST(u32x4, v_ring + 2 * G::kTileBytes + kBlk + i) = u32x4{0u, 0u, 0u, 0u};
+  }
 
   // ---- Q fragments: B operand of S^T = K Q^T: lane (r, h) holds Q[row r][16*ks + 8*h + 0..7] ----
-  const int qrow = (int)qt * kBr + wave * kRowsPerWave + r;
-  f16x8 qf[G::kKSteps];
+  int qrow[kQB];
+  f16x8 qf[kQB][G::kKSteps];
 #pragma unroll
-  for (int ks = 0; ks < G::kKSteps; ++ks) {
-    const int col = 16 * ks + 8 * h;
-    if constexpr (FAST) {
-      const uint32_t off = (col < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)col) * 2u : kOob;
-      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
-      qf[ks] = __builtin_bit_cast(f16x8, raw);
-    } else {
+  for (int q = 0; q < kQB; ++q) {
+    qrow[q] = (int)qt * kBr + wave * kRowsPerWave + q * 32 + r;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint32_t off =
-            (col + j < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)(col + j)) * (uint32_t)sizeof(T) : kOob;
-        qf[ks][j] = load_elem<T>(q_rs, off);
+    for (int ks = 0; ks < G::kKSteps; ++ks) {
+      const int col = 16 * ks + 8 * h;
+      if constexpr (FAST) {
+        const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * 2u : kOob;
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
+        qf[q][ks] = __builtin_bit_cast(f16x8, raw);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t off =
+              (col + j < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)(col + j)) * (uint32_t)sizeof(T) : kOob;
+          qf[q][ks][j] = load_elem<T>(q_rs, off);
+        }
       }
     }
   }
 
-  f32x16 o[G::kDvBlocks];
+  // Q and O^T live in accumulation registers from here on.
+  f32x16 o[kQB][G::kDvBlocks];
 #pragma unroll
-  for (int b = 0; b < G::kDvBlocks; ++b) {
+  for (int q = 0; q < kQB; ++q) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
+    for (int ks = 0; ks < G::kKSteps; ++ks) asm volatile("" : "+a"(qf[q][ks]));
+#pragma unroll
+    for (int b = 0; b < G::kDvBlocks; ++b) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[q][b][i] = 0.f;
+      asm volatile("" : "+a"(o[q][b]));
+    }
   }
-  SoftmaxState st;
-  st.m = -3.0e38f;  // finite, so that the first rescale factor is exp2(-huge) = 0, never NaN
-  st.l = 0.f;
-  st.alpha = 1.f;
   const float c = p.scale_log2e;
-  const bool ragged = (N % kBc) != 0;
+  const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
 
   staged_barrier();
 
-  const LaneAddr<D> la = make_lane_addr<D>(lane);
-  f32x16 sA, sB;
-  f16x8 pA[2], pB[2];
-  constexpr int kBlk = 32 * G::kRowBytes;  // bytes of one 32-key block inside a tile
-
-  // S(0)
-  matrix_section<D, false, true>(nullptr, pA, o, k_ring, qf, sA, la);
-
-  // One tile = two steps.  VF (wave-uniform): run the vector section before the matrix section.
-  // The two waves that share a SIMD (wave w and w + 4) use opposite orders, so that one of them
-  // feeds the matrix pipe while the other one runs its softmax.
-  auto tile_steps = [&](auto vf_tag, auto first_tag, auto last_tag, int t, int slot) __attribute__((always_inline)) {
-    constexpr bool VF = decltype(vf_tag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;  // t == 0: there is no previous block to multiply
-    constexpr bool LAST = decltype(last_tag)::value;    // t == nt-1: there is no next tile to score
-    lds_char* const k_cur = k_ring + slot * G::kTileBytes;
-    lds_char* const k_nxt = k_ring + (slot ^ 1) * G::kTileBytes;
-    lds_char* const v_cur = v_ring + slot * G::kTileBytes;
-    lds_char* const v_prv = v_ring + (slot ^ 1) * G::kTileBytes;
-    const bool masked = LAST && ragged;
-    bool rs;
-    // step 2t: PV(2t-1) | QK(2t+1) | softmax(2t)
-    if constexpr (VF) {
-      rs = softmax_block<D>(sA, pA, st, c, t * kBc, N, masked, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      matrix_section<D, !FIRST, true>(v_prv + kBlk, pB, o, k_cur + kBlk, qf, sB, la);
-    } else {
-      matrix_section<D, !FIRST, true>(v_prv + kBlk, pB, o, k_cur + kBlk, qf, sB, la);
-      rs = softmax_block<D>(sA, pA, st, c, t * kBc, N, masked, lane);
+  // ---- prologue: S(0), its row max, and the first K fragments of block 1 ------------------------
+  f32x16 sA[kQB], sB[kQB];
+  f16x8 pA[kQB][2], pB[kQB][2];
+  f16x8 ka[G::kKHold];
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pB[q][0][j] = (f16)0.f;
+      pB[q][1][j] = (f16)0.f;
     }
-    if (rs) rescale_o<D>(o, st.alpha);
-    staged_barrier();
-    if (t + 2 < nt) stage_k(t + 2);
-    if (t + 1 < nt) stage_v(t + 1);
-    // step 2t+1: PV(2t) | QK(2t+2) | softmax(2t+1)
-    if constexpr (VF) {
-      rs = softmax_block<D>(sB, pB, st, c, t * kBc + 32, N, masked, lane);
-      __builtin_amdgcn_sched_barrier(0);
-      matrix_section<D, true, !LAST>(v_cur, pA, o, k_nxt, qf, sA, la);
-    } else {
-      matrix_section<D, true, !LAST>(v_cur, pA, o, k_nxt, qf, sA, la);
-      rs = softmax_block<D>(sB, pB, st, c, t * kBc + 32, N, masked, lane);
-    }
-    if (rs) rescale_o<D>(o, st.alpha);
-  };
-  auto sweep = [&](auto vf_tag) __attribute__((always_inline)) {
-    constexpr std::true_type yes{};
-    constexpr std::false_type no{};
-    if (nt == 1) {
-      tile_steps(vf_tag, yes, yes, 0, 0);
-    } else {
-      tile_steps(vf_tag, yes, no, 0, 0);
-      int t = 1;
-      for (; t + 2 < nt; t += 2) {  // slots alternate 1, 0: constant LDS offsets inside the loop
-        tile_steps(vf_tag, no, no, t, 1);
-        tile_steps(vf_tag, no, no, t + 1, 0);
-      }
-      if (t + 1 < nt) {
-        tile_steps(vf_tag, no, no, t, 1);
-        ++t;
-      }
-      tile_steps(vf_tag, no, yes, t, t & 1);
-    }
-  };
-  if (wave >= kWaves / 2) {
-    sweep(std::true_type{});
-  } else {
-    sweep(std::false_type{});
   }
-  // PV of the last block
-  matrix_section<D, true, false>(v_ring + ((nt - 1) & 1) * G::kTileBytes + kBlk, pB, o, nullptr, qf, sA, la);
+#pragma unroll
+  for (int ks = 0; ks < G::kKHold; ++ks) ka[ks] = read_k_frag<D>(0u, la, ks);
+#pragma unroll
+  for (int ks = 0; ks < G::kKSteps; ++ks) {
+#pragma unroll
+    for (int q = 0; q < kQB; ++q) {
+      if (ks == 0) {
+        mfma_s_first<true>(sA[q], ka[ks % G::kKHold], qf[q][ks]);
+      } else {
+        mfma_s<true>(sA[q], ka[ks % G::kKHold], qf[q][ks]);
+      }
+    }
+    if (ks + G::kKHold < G::kKSteps) {
+      ka[ks % G::kKHold] = read_k_frag<D>(0u, la, ks + G::kKHold);
+    } else {
+      ka[ks % G::kKHold] = read_k_frag<D>((uint32_t)kBlk, la, ks + G::kKHold - G::kKSteps);
+    }
+  }
+  mfma_drain();
+  SoftmaxState st[kQB];
+  bool pending = false;
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) {
+    mask_scores(sA[q], 0, N, lane);
+    st[q].m = block_row_max(sA[q]);  // block 0 always holds key 0, so this is finite
+    st[q].mc = st[q].m * c;
+    st[q].l = 0.f;
+    st[q].alpha = 1.f;
+    st[q].mx_next = st[q].m;
+  }
+
+  // One tile iteration.  SLOT >= 0: ring slot of tile t known at compile time (all LDS offsets
+  // become instruction immediates); SLOT < 0: taken from `slot_rt`.
+  auto tile_iter = [&](auto slot_tag, auto masked_tag, auto last_tag, int t, int slot_rt) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;
+    const int s0 = SLOT >= 0 ? SLOT : slot_rt;
+    const int s1 = s0 == 2 ? 0 : s0 + 1;  // slot of tile t+1
+    const int s2 = s1 == 2 ? 0 : s1 + 1;  // slot of tile t+2 == slot of tile t-1
+    if (t + 2 < nt) stage_k(t + 2, s2);
+    if (t + 1 < nt) stage_v(t + 1, s1);
+    const uint32_t k_cur = (uint32_t)(s0 * G::kTileBytes);  // byte offsets into the K / V ring
+    const uint32_t k_nxt = (uint32_t)(s1 * G::kTileBytes);
+    const uint32_t v_cur = (uint32_t)(s0 * G::kTileBytes);
+    const uint32_t v_prv = (uint32_t)(s2 * G::kTileBytes);
+    pipeline_step<D, !FAST, true, !LAST, MASKED>(k_cur + kBlk, v_prv + kBlk, k_nxt, la, qf, ka, o, sA, sB, pB, pA, st, c,
+                                          t * kBc + 32, N, lane);
+    step_end<D>(o, st, pending, c, true);
+    pipeline_step<D, !FAST, !LAST, !LAST, MASKED>(k_nxt, v_cur, k_nxt + kBlk, la, qf, ka, o, sB, sA, pA, pB, st, c,
+                                           (t + 1) * kBc, N, lane);
+    step_end<D>(o, st, pending, c, !LAST);
+    staged_barrier();
+  };
+  using std::integral_constant;
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
+  int t = 0;
+  // main loop: whole triples of tiles (ring slots 0, 1, 2) that end before the last two tiles
+  for (; t + 5 <= nt; t += 3) {
+    tile_iter(integral_constant<int, 0>{}, no, no, t, 0);
+    tile_iter(integral_constant<int, 1>{}, no, no, t + 1, 1);
+    tile_iter(integral_constant<int, 2>{}, no, no, t + 2, 2);
+  }
+  // remaining tiles (at most four, among them the possibly ragged last one): runtime slot, key mask
+  // evaluated
+  for (; t + 1 < nt; ++t) tile_iter(integral_constant<int, -1>{}, yes, no, t, t % 3);
+  tile_iter(integral_constant<int, -1>{}, yes, yes, t, t % 3);
+  // PV of the last block (its pending rescale, if any, was applied by the last step_end)
+  {
+    mfma_drain();
+    const uint32_t vb = (uint32_t)(((nt - 1) % 3) * G::kTileBytes + kBlk);
+#pragma unroll
+    for (int b = 0; b < G::kDvBlocks; ++b) {
+      const f16x8 v0 = read_v_frag<D>(vb, la, b, 0);
+      const f16x8 v1 = read_v_frag<D>(vb, la, b, 1);
+#pragma unroll
+      for (int q = 0; q < kQB; ++q) {
+        mfma_o<true>(o[q][b], v0, pB[q][0]);
+        mfma_o<true>(o[q][b], v1, pB[q][1]);
+      }
+    }
+    mfma_drain();
+  }
 
   // ---- epilogue: O = O^T / l, registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 ----------
-  const HalfPair lp = both_halves(st.l);
-  const float inv = 1.0f / (lp.lo + lp.hi);
 #pragma unroll
-  for (int b = 0; b < G::kDvBlocks; ++b) {
+  for (int q = 0; q < kQB; ++q) {
+    const HalfPair lp = both_halves(st[q].l);
+    const float inv = 1.0f / (lp.lo + lp.hi);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int dv = 32 * b + 8 * g + 4 * h;
-      if constexpr (FAST) {
-        f16x4 pk;
+    for (int b = 0; b < G::kDvBlocks; ++b) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = (f16)(o[b][4 * g + j] * inv);
-        const uint32_t off = (dv < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), o_rs, off, 0, 0);
-      } else {
+      for (int g = 0; g < 4; ++g) {
+        const int dv = 32 * b + 8 * g + 4 * h;
+        if constexpr (FAST) {
+          f16x4 pk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t off =
-              (dv + j < d) ? ((uint32_t)qrow * (uint32_t)d + (uint32_t)(dv + j)) * (uint32_t)sizeof(T) : kOob;
-          store_elem(o_rs, off, (T)(o[b][4 * g + j] * inv));
+          for (int j = 0; j < 4; ++j) pk[j] = (f16)(o[q][b][4 * g + j] * inv);
+          const uint32_t off = (dv < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), o_rs, off, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t off = (dv + j < d)
+                                     ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)(dv + j)) * (uint32_t)sizeof(T)
+                                     : kOob;
+            store_elem(o_rs, off, (T)(o[q][b][4 * g + j] * inv));
+          }
         }
       }
     }
