@@ -358,7 +358,6 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
   float rs[kQB];
   float nmc[kQB];
   float mx[kQB];
-  float xprev = 0.f;
 #pragma unroll
   for (int q = 0; q < kQB; ++q) {
     rs[q] = 0.f;
@@ -366,28 +365,37 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
     mx[q] = 0.f;
   }
 
-  // exp(j) share of slot n: element g = n*EPS + e of the 16*kQB elements (query block g/16)
+  // exp(j) share of slot n, software-pipelined over the slots so that no instruction consumes a
+  // result produced in the same slot (a lone wave has nothing else to issue while it waits for one):
+  //   element g+1: a = s*c - m*c        element g: x = exp2(a from the slot before)
+  //   element g-1: row sum += x, and once both halves of a pair exist: pack to fp16
+  // g = n*EPS + e runs over the 16*kQB elements of the wave's query blocks (block g/16).
+  float t_arg = __builtin_fmaf(s_cur[0][0], c, nmc[0]);  // element 0
+  float t_exp = 0.f, t_exp_prev = 0.f;
+  auto finish = [&](int g) __attribute__((always_inline)) {  // element g: sum and (odd g) pack
+    const int q = g / 16, i = g % 16;
+    rs[q] += t_exp;
+    if ((i & 1) != 0) {
+      f16x2 pk;
+      pk[0] = (f16)t_exp_prev;
+      pk[1] = (f16)t_exp;
+      // pin the packed pair and the running sum here: otherwise the compiler keeps the fp32
+      // exponentials alive and converts / adds them several slots later
+      uint32_t w = __builtin_bit_cast(uint32_t, pk);
+      asm volatile("" : "+v"(w), "+v"(rs[q]));
+      pk = __builtin_bit_cast(f16x2, w);
+      p_cur[q][i >> 3][(i & 7) - 1] = pk[0];
+      p_cur[q][i >> 3][i & 7] = pk[1];
+    }
+    t_exp_prev = t_exp;
+  };
   auto exp_share = [&](int n) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < EPS; ++e) {
       const int g = n * EPS + e;
-      const int q = g / 16, i = g % 16;
-      const float x = fast_exp2(__builtin_fmaf(s_cur[q][i], c, nmc[q]));
-      rs[q] += x;
-      if ((i & 1) == 0) {
-        xprev = x;
-      } else {
-        f16x2 pk;
-        pk[0] = (f16)xprev;
-        pk[1] = (f16)x;
-        // pin the packed pair and the running sum to this slot: otherwise the compiler keeps the
-        // fp32 exponentials alive and converts / adds them several slots later
-        uint32_t w = __builtin_bit_cast(uint32_t, pk);
-        asm volatile("" : "+v"(w), "+v"(rs[q]));
-        pk = __builtin_bit_cast(f16x2, w);
-        p_cur[q][i >> 3][(i & 7) - 1] = pk[0];
-        p_cur[q][i >> 3][i & 7] = pk[1];
-      }
+      if (g > 0) finish(g - 1);
+      t_exp = fast_exp2(t_arg);
+      if (g + 1 < 16 * kQB) t_arg = __builtin_fmaf(s_cur[(g + 1) / 16][(g + 1) % 16], c, nmc[(g + 1) / 16]);
     }
   };
   // row-max micro-op u (0 .. MAX_OPS-1) of s_nxt: chunk u%5 < 4 folds registers 4c..4c+3, u%5 == 4
@@ -418,6 +426,7 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
         } else {
           mfma_s<PAD>(s_nxt[q], ka[ks % KH], qf[q][ks]);
         }
+        __builtin_amdgcn_sched_barrier(0);  // the MFMA opens its slot, the fillers follow it
         if (q == kQB - 1) {
           if (ks + KH < KS) {
             ka[ks % KH] = read_k_frag<D>(kb, la, ks + KH);
@@ -449,6 +458,7 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
         const int pslot = (b * 2 + ks) * kQB + q;
         const int vi = (b & 1) * 2 + ks;
         mfma_o<PAD>(o[q][b], va[vi], p_prev[q][ks]);
+        __builtin_amdgcn_sched_barrier(0);
         if (q == kQB - 1 && b + 2 < NB) va[vi] = read_v_frag<D>(vb, la, b + 2, ks);
         exp_share(QK_SLOTS + pslot);
         if constexpr (HAS_QK) {
@@ -461,6 +471,7 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
       }
     }
   }
+  finish(16 * kQB - 1);
 #pragma unroll
   for (int q = 0; q < kQB; ++q) st[q].l += rs[q];
 }
@@ -475,7 +486,7 @@ __device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], S
 #pragma unroll
   for (int q = 0; q < kQB; ++q) need = need || ((st[q].mx_next - st[q].m) * c > kDeferLog2);
   const bool any_need = has_next && (__builtin_amdgcn_ballot_w64(need) != 0);
-  if (pending || any_need) {
+  if (__builtin_expect(pending || any_need, 0)) {  // rare: keep it out of the fall-through path
     if (pending) {
       mfma_drain();  // the last P V MFMAs of the step must have written O
 #pragma unroll
