@@ -43,27 +43,46 @@ def attention_flops(B, H, N, d):
     return 4.0 * B * H * N * N * d    # QK^T + PV, non-causal
 
 
-def cpu_baseline(oracle, shape, budget_heads=4):
-    """Time the CPU oracle on `budget_heads` heads of the workload; report whole-workload-equivalent
-    TFLOP/s (heads are independent, so time scales linearly in B*H)."""
+def cpu_baseline(oracle, shape, target_seconds=12.0):
+    """Time the CPU oracle on a bounded head sample of the workload (about `target_seconds` of CPU
+    work, sized from a 4-head calibration run); report TFLOP/s.  Heads are independent, so the
+    whole-workload time is the sample time scaled by B*H / heads."""
     import numpy as np
 
     B, H, N, d = shape
-    heads = min(budget_heads, B * H)
     rng = np.random.default_rng(0)
-    q, k, v = (oracle.round_f16(rng.standard_normal((1, heads, N, d)).astype(np.float32)) for _ in range(3))
-    oracle.attn_naive(q[:, :1, :256], k[:, :1, :256], v[:, :1, :256])  # spin up the OpenMP pool
-    t0 = time.perf_counter()
-    oracle.attn_naive(q, k, v)
-    dt = time.perf_counter() - t0
+
+    def timed(heads):
+        q, k, v = (oracle.round_f16(rng.standard_normal((1, heads, N, d)).astype(np.float32)) for _ in range(3))
+        t0 = time.perf_counter()
+        oracle.attn_naive(q, k, v)
+        return time.perf_counter() - t0
+
+    timed(1)                                   # spin up the OpenMP pool
+    probe = min(4, B * H)
+    per_head = timed(probe) / probe
+    heads = int(max(probe, min(B * H, round(target_seconds / per_head))))
+    dt = timed(heads)
     return {
-        "value": attention_flops(1, heads, N, d) / dt / 1e12,
+        "value": round(attention_flops(1, heads, N, d) / dt / 1e12, 4),
         "unit": "TFLOP/s",
         "cores": oracle.num_threads(),
         "kind": "port",
-        "sample": f"{heads} of {B * H} heads of ({B},{H},{N},{d}), fp32 softmax(QK^T/sqrt(d))V, "
+        "sample": f"{heads} of {B * H} heads of ({B},{H},{N},{d}), fp32 softmax(QK^T/sqrt(d))V on fp16-rounded inputs, "
                   f"{dt:.2f} s; whole workload would take {dt * B * H / heads:.1f} s",
     }
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction for wide streaming
+    reads applied), or None when no pass was recorded for this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -161,7 +180,7 @@ def main():
                 "peak": PEAK_TFLOPS_FP16_DENSE,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
-                "traffic": None,
+                "traffic": measured_traffic(args.workload),
                 "kernel": "flash_hip::attn_fwd_kernel",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops,

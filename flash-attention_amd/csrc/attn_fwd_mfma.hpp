@@ -126,7 +126,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // v_accvgpr_read per MFMA).
 // The price: the compiler does not know these statements are MFMAs and pads no hazards for them.
 // The kernel keeps every consumer of an MFMA result at least two MFMAs behind its producer; where
-// that is not structurally guaranteed (prologue, rescale path, epilogue) it calls mfma_drain().
+// that is not structurally guaranteed (prologue, rescale path, epilogue) it calls mfma_drain_acc() / mfma_drain_s().
 // A register copy that the compiler places directly in front of such a statement (it does so when it
 // keeps an operand in the other register file) would be read too early: v_accvgpr_write -> MFMA
 // needs two wait states.  PAD = true prefixes them to every MFMA; the tuned kernels (PAD = false)
@@ -159,7 +159,22 @@ __device__ __forceinline__ void mfma_o(f32x16& acc, const f16x8& a, const f16x8&
   }
 }
 // Wait states that cover the result latency of the last MFMA before other instructions read it.
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// The registers whose readers must stay behind the wait are operands of the statement: a bare
+// statement orders nothing, the compiler is free to move register reads across it.
+template <int NQ, int NB>
+__device__ __forceinline__ void mfma_drain_acc(f32x16 (&o)[NQ][NB]) {
+  static_assert(NQ == 2 && (NB == 2 || NB == 4), "operand list is written out for these shapes");
+  if constexpr (NB == 4) {
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]),
+                   "+a"(o[1][2]), "+a"(o[1][3]));
+  } else {
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[1][0]), "+a"(o[1][1]));
+  }
+}
+__device__ __forceinline__ void mfma_drain_s(f32x16 (&s)[2]) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
+}
 
 // Raw buffer descriptor (stride 0, range-checked against `bytes`) as four wave-uniform dwords.
 typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
@@ -335,8 +350,9 @@ __device__ __forceinline__ float block_row_max(const f32x16& s) {
 //   PV slots (2*NB * kQB)  PV(j-1): O^T[q][b] += V_{j-1}^T[b] * P_{j-1}[q]^T, V fragments two dv blocks
 //                          ahead; row max of s_nxt once the QK chain has drained
 //   all slots              exp(j): a share of p_cur = exp2(s_cur*c - m*c) and of the row sum
-template <int D, bool PAD, bool HAS_QK, bool HAS_PRELOAD, bool MASKED>
-__device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t kb_next, const LaneAddr<D>& la,
+template <int D, bool PAD, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, typename Hook>
+__device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uint32_t vb, uint32_t kb_next,
+                                              const LaneAddr<D>& la,
                                               const f16x8 (&qf)[kQB][Geom<D>::kKSteps], f16x8 (&ka)[Geom<D>::kKHold],
                                               f32x16 (&o)[kQB][Geom<D>::kDvBlocks], const f32x16 (&s_cur)[kQB],
                                               f32x16 (&s_nxt)[kQB], const f16x8 (&p_prev)[kQB][2],
@@ -445,6 +461,7 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
         va[3] = read_v_frag<D>(vb, la, 1, 1);
       }
       exp_share(n);
+      hook(n);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -461,6 +478,7 @@ __device__ __forceinline__ void pipeline_step(uint32_t kb, uint32_t vb, uint32_t
         __builtin_amdgcn_sched_barrier(0);
         if (q == kQB - 1 && b + 2 < NB) va[vi] = read_v_frag<D>(vb, la, b + 2, ks);
         exp_share(QK_SLOTS + pslot);
+        hook(QK_SLOTS + pslot);
         if constexpr (HAS_QK) {
 #pragma unroll
           for (int u = 0; u < MAX_OPS; ++u) {
@@ -488,7 +506,7 @@ __device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], S
   const bool any_need = has_next && (__builtin_amdgcn_ballot_w64(need) != 0);
   if (__builtin_expect(pending || any_need, 0)) {  // rare: keep it out of the fall-through path
     if (pending) {
-      mfma_drain();  // the last P V MFMAs of the step must have written O
+      mfma_drain_acc(o);  // the last P V MFMAs of the step must have written O
 #pragma unroll
       for (int q = 0; q < kQB; ++q) rescale_o<D>(o[q], st[q].alpha);
     }
@@ -697,7 +715,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
       ka[ks % G::kKHold] = read_k_frag<D>((uint32_t)kBlk, la, ks + G::kKHold - G::kKSteps);
     }
   }
-  mfma_drain();
+  mfma_drain_s(sA);
   SoftmaxState st[kQB];
   bool pending = false;
 #pragma unroll
@@ -719,16 +737,43 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     const int s0 = SLOT >= 0 ? SLOT : slot_rt;
     const int s1 = s0 == 2 ? 0 : s0 + 1;  // slot of tile t+1
     const int s2 = s1 == 2 ? 0 : s1 + 1;  // slot of tile t+2 == slot of tile t-1
-    if (t + 2 < nt) stage_k(t + 2, s2);
-    if (t + 1 < nt) stage_v(t + 1, s1);
+    auto no_hook = [](int) __attribute__((always_inline)) {};
+    // staging spread over the slots of the first step: piece i of the wave at slot i * spacing + 1
+    auto dma_hook = [&](int n) __attribute__((always_inline)) {
+      if constexpr (FAST) {
+        constexpr int kSlotsPerStep = G::kKSteps * kQB + 2 * G::kDvBlocks * kQB;
+        constexpr int kSpacing = kSlotsPerStep / (2 * G::kPiecesPerWave);
+        if (n % kSpacing == 1) {
+          const int i = n / kSpacing;
+          if (i < G::kPiecesPerWave) {
+            if (t + 2 < nt) {
+              const int pc = wave * G::kPiecesPerWave + i;
+              const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(k_ring + s2 * G::kTileBytes + pc * 1024));
+              dma_piece(k_srd, dma_off[i] + (uint32_t)(t + 2) * tile_step, lds_base);
+            }
+          } else {
+            if (t + 1 < nt) {
+              const int pc = wave * G::kPiecesPerWave + (i - G::kPiecesPerWave);
+              const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(v_ring + s1 * G::kTileBytes + pc * 1024));
+              dma_piece(v_srd, dma_off[i - G::kPiecesPerWave] + (uint32_t)(t + 1) * tile_step, lds_base);
+            }
+          }
+        }
+      } else {
+        if (n == 0) {
+          if (t + 2 < nt) stage_k(t + 2, s2);
+          if (t + 1 < nt) stage_v(t + 1, s1);
+        }
+      }
+    };
     const uint32_t k_cur = (uint32_t)(s0 * G::kTileBytes);  // byte offsets into the K / V ring
     const uint32_t k_nxt = (uint32_t)(s1 * G::kTileBytes);
     const uint32_t v_cur = (uint32_t)(s0 * G::kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * G::kTileBytes);
-    pipeline_step<D, !FAST, true, !LAST, MASKED>(k_cur + kBlk, v_prv + kBlk, k_nxt, la, qf, ka, o, sA, sB, pB, pA, st, c,
+    pipeline_step<D, !FAST, true, !LAST, MASKED>(dma_hook, k_cur + kBlk, v_prv + kBlk, k_nxt, la, qf, ka, o, sA, sB, pB, pA, st, c,
                                           t * kBc + 32, N, lane);
     step_end<D>(o, st, pending, c, true);
-    pipeline_step<D, !FAST, !LAST, !LAST, MASKED>(k_nxt, v_cur, k_nxt + kBlk, la, qf, ka, o, sB, sA, pA, pB, st, c,
+    pipeline_step<D, !FAST, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlk, la, qf, ka, o, sB, sA, pA, pB, st, c,
                                            (t + 1) * kBc, N, lane);
     step_end<D>(o, st, pending, c, !LAST);
     staged_barrier();
@@ -749,7 +794,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
   tile_iter(integral_constant<int, -1>{}, yes, yes, t, t % 3);
   // PV of the last block (its pending rescale, if any, was applied by the last step_end)
   {
-    mfma_drain();
+    mfma_drain_acc(o);
     const uint32_t vb = (uint32_t)(((nt - 1) % 3) * G::kTileBytes + kBlk);
 #pragma unroll
     for (int b = 0; b < G::kDvBlocks; ++b) {
@@ -761,7 +806,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
         mfma_o<true>(o[q][b], v1, pB[q][1]);
       }
     }
-    mfma_drain();
+    mfma_drain_acc(o);
   }
 
   // ---- epilogue: O = O^T / l, registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 ----------

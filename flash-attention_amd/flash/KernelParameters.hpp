@@ -27,8 +27,9 @@ class KernelParametersBase {
   virtual ~KernelParametersBase() = default;
 };
 
-// Geometry of the wave64 MFMA kernel: 8 waves x 32 query rows per workgroup (Br = 256), 64-row
-// K/V tiles (Bc), head dim padded to 64 or 128, K and V double-buffered in LDS.
+// Geometry of the wave64 MFMA kernel: 4 waves (one per SIMD) x 64 query rows per workgroup
+// (Br = 256), 64-row K/V tiles (Bc), head dim padded to 64 or 128, rings of three K and three V
+// tiles in LDS.
 // Replaces MMAQregParameters / MMAQregAsyncParameters (reference flash/KernelParameters.hpp:332-381).
 class MFMAQregParameters : public KernelParametersBase {
   flash_launch_info info_{};
@@ -40,7 +41,7 @@ class MFMAQregParameters : public KernelParametersBase {
   }
   static constexpr uint32_t rowsPerTileQ() { return 256; }
   static constexpr uint32_t rowsPerTileK() { return 64; }
-  static constexpr uint32_t wavesPerBlock() { return 8; }
+  static constexpr uint32_t wavesPerBlock() { return 4; }
   dim3 tileSize() override { return dim3(info_.tile_kv, info_.tile_q, info_.tile_d); }
   uint32_t sramSize() override { return info_.lds_bytes; }
   dim3 blockDim() override { return dim3(info_.block_x, info_.block_y); }

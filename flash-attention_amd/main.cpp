@@ -215,7 +215,7 @@ int run_cpu_plumbing() {
   std::cout << "Tile size: " << tile.x << ", " << tile.y << ", " << tile.z << "\nBlock dim: " << block.x << ", "
             << block.y << "\nGrid dim: " << grid.x << ", " << grid.y << ", " << grid.z << "\nLDS/workgroup "
             << params->sramSize() / 1024. << " KiB" << std::endl;
-  ok &= tile.z == 64 && block.x * block.y == 512 && grid.z == 1;
+  ok &= tile.z == 64 && block.x * block.y == 256 && grid.z == 1;
   auto throws = [](flash::KernelType kt, int d) {
     try {
       flash::KernelParametersFactory::create(1, 1, 64, d, kt);

@@ -69,12 +69,28 @@ static Cmp compare(const float* res, const float* ref, size_t n) {
   return c;
 }
 
-static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool fp32_io) {
+// spike > 0: some keys are made parallel to some query rows with a large gain, so that the running
+// max of those rows jumps by far more than any deferral threshold at chosen tiles (forces the
+// online-softmax rescale, which bounded random data never triggers)
+static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool fp32_io, int spike = 0) {
   const size_t n = (size_t)(B * H * N * d);
   std::vector<float> q(n), k(n), v(n), qr(n), kr(n), vr(n), ref(n), out(n);
   fill_normal(q);
   fill_normal(k);
   fill_normal(v);
+  if (spike > 0) {
+    for (int64_t hd = 0; hd < B * H; ++hd) {
+      for (int sidx = 0; sidx < spike; ++sidx) {
+        const int64_t row = (int64_t)(urand() * N), key = (int64_t)(urand() * N);
+        const float gain = 6.0f + 2.0f * (float)sidx;
+        const float* qrow = &q[(size_t)(hd * N + row) * d];
+        double nrm = 0;
+        for (int64_t x = 0; x < d; ++x) nrm += (double)qrow[x] * qrow[x];
+        nrm = std::sqrt(nrm) + 1e-6;
+        for (int64_t x = 0; x < d; ++x) k[(size_t)(hd * N + key) * d + x] = (float)(gain * qrow[x] / nrm);
+      }
+    }
+  }
   std::vector<uint16_t> qh(n), kh(n), vh(n), oh(n);
   oracle_f32_to_f16_bits(q.data(), qh.data(), n);
   oracle_f32_to_f16_bits(k.data(), kh.data(), n);
@@ -237,6 +253,12 @@ int main(int argc, char** argv) {
       all &= run_shape(s.B, s.H, s.N, s.d, kt, false);
     }
     all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, true);
+  }
+  printf("forced rescale (spiked keys)\n");
+  const Shape spiked[] = {{1, 2, 640, 128}, {2, 2, 1000, 64}, {1, 1, 2048, 128}, {1, 2, 333, 72}};
+  for (const Shape& s : spiked) {
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_MMA_QREG_ASYNC, false, 6);
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, true, 6);
   }
   printf(all ? "ALL PASS\n" : "SOME FAILED\n");
   return all ? 0 : 1;
