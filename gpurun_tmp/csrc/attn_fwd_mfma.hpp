@@ -51,11 +51,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 #define FLASH_LDS_CAST(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-#ifndef FLASH_QB
-#define FLASH_QB 2
-#endif
-constexpr int kQB = FLASH_QB;               // 32-row query blocks per wave
-constexpr int kWaves = 8 / kQB;             // waves per workgroup: kQB = 2 -> one per SIMD, 1 -> two per SIMD
+constexpr int kWaves = 4;                   // waves per workgroup, one per SIMD
+constexpr int kQB = 2;                      // 32-row query blocks per wave
 constexpr int kRowsPerWave = 32 * kQB;      // 64 query rows per wave
 constexpr int kBr = kWaves * kRowsPerWave;  // 256 query rows per workgroup
 constexpr int kBc = 64;                     // key/value rows per LDS tile
@@ -74,6 +71,7 @@ struct FwdParams {
   int nqt;            // query tiles per head = ceil(N / kBr)
   uint32_t total_wg;  // B * H * nqt
   float scale_log2e;  // softmax_scale * log2(e)
+  unsigned long long* dbg;
 };
 
 template <int D>
@@ -166,12 +164,8 @@ __device__ __forceinline__ void mfma_o(f32x16& acc, const f16x8& a, const f16x8&
 // statement orders nothing, the compiler is free to move register reads across it.
 template <int NQ, int NB>
 __device__ __forceinline__ void mfma_drain_acc(f32x16 (&o)[NQ][NB]) {
-  static_assert((NQ == 1 || NQ == 2) && (NB == 2 || NB == 4), "operand list is written out for these shapes");
-  if constexpr (NQ == 1 && NB == 4) {
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]));
-  } else if constexpr (NQ == 1) {
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]));
-  } else if constexpr (NB == 4) {
+  static_assert(NQ == 2 && (NB == 2 || NB == 4), "operand list is written out for these shapes");
+  if constexpr (NB == 4) {
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]),
                    "+a"(o[1][2]), "+a"(o[1][3]));
@@ -182,7 +176,6 @@ __device__ __forceinline__ void mfma_drain_acc(f32x16 (&o)[NQ][NB]) {
 __device__ __forceinline__ void mfma_drain_s(f32x16 (&s)[2]) {
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
 }
-__device__ __forceinline__ void mfma_drain_s(f32x16 (&s)[1]) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0])); }
 
 // Raw buffer descriptor (stride 0, range-checked against `bytes`) as four wave-uniform dwords.
 typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
@@ -498,11 +491,11 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uin
         }
       }
       // V fragments of the first two dv blocks, a few slots before the PV slots begin
-      if (n == (QK_SLOTS >= 6 ? QK_SLOTS - 6 : 0)) {
+      if (n == QK_SLOTS - 6) {
         va[0] = read_v_frag<D>(vb, la, 0, 0);
         va[1] = read_v_frag<D>(vb, la, 0, 1);
       }
-      if (n == (QK_SLOTS >= 6 ? QK_SLOTS - 4 : 1)) {
+      if (n == QK_SLOTS - 4) {
         va[2] = read_v_frag<D>(vb, la, 1, 0);
         va[3] = read_v_frag<D>(vb, la, 1, 1);
       }
@@ -578,11 +571,7 @@ __device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], S
         bq[q] = bias_fragment(r, lane);
       }
       // the rebuilt fragments are MFMA operands of the very next instruction group
-      if constexpr (kQB == 2) {
-        asm volatile("s_nop 4" : "+a"(bq[0]), "+a"(bq[kQB - 1]));
-      } else {
-        asm volatile("s_nop 4" : "+a"(bq[0]));
-      }
+      asm volatile("s_nop 4" : "+a"(bq[0]), "+a"(bq[1]));
       pending = true;
     }
   }
@@ -613,6 +602,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
   // Work item: consecutive items = query tiles of one head; items are dealt to the 8 XCDs in
   // contiguous ranges (workgroup ids that are equal mod 8 share an XCD and hence an L2), so the
   // workgroups that stream the same K/V run on the same L2 at about the same time.
+  const unsigned long long T0 = __builtin_amdgcn_s_memtime();
   const uint32_t bid = blockIdx.x;
   const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
   const uint32_t per = p.total_wg >> 3, rem = p.total_wg & 7u;
@@ -802,6 +792,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     st[q].mx_next = 0.f;
   }
 
+  const unsigned long long T1 = __builtin_amdgcn_s_memtime();
   // One tile iteration.  SLOT >= 0: ring slot of tile t known at compile time (all LDS offsets
   // become instruction immediates); SLOT < 0: taken from `slot_rt`.
   auto tile_iter = [&](auto slot_tag, auto masked_tag, auto last_tag, int t, int slot_rt) __attribute__((always_inline)) {
@@ -868,6 +859,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
   // evaluated
   for (; t + 1 < nt; ++t) tile_iter(integral_constant<int, -1>{}, yes, no, t, t % 3);
   tile_iter(integral_constant<int, -1>{}, yes, yes, t, t % 3);
+  const unsigned long long T2 = __builtin_amdgcn_s_memtime();
   // PV of the last block (its pending rescale, if any, was applied by the last step_end)
   {
     mfma_drain_acc(o);
@@ -912,6 +904,14 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
         }
       }
     }
+  }
+  const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long T4 = __builtin_amdgcn_s_memtime();
+  if (p.dbg && lane == 0) {
+    unsigned long long* d = p.dbg + ((size_t)bid * 4 + wave) * 8;
+    d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3; d[4] = T4;
+    d[5] = __builtin_amdgcn_s_getreg(4 << 11 | 0 << 6 | 20); // HW_ID-ish (unused)
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }

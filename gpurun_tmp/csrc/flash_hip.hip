@@ -1,0 +1,189 @@
+// C-ABI entry points of libflash_hip.so (declared in include/flash_hip.h): argument checking,
+// tile selection, launch.  Host-side counterpart of the reference's flash::forward dispatch and
+// launchKernel (reference flash/launch.cu:130-183, 185-324) and of KernelParametersFactory
+// (reference flash/KernelParameters.hpp:383-422).
+#include "../../include/flash_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "attn_fwd_mfma.hpp"
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+using namespace flash_hip;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+const char* const kNames[FLASH_KT_COUNT] = {
+    "naive1D",   "scalar2D",         "scalar2D_row_tile", "warp_wmma", "block_wmma", "wmma_row_block",
+    "block_wmma_async", "mma", "mma_swizzle",       "mma_qreg",  "mma_qreg_f32x4load", "mma_qreg_async"};
+
+struct Plan {
+  int tile_d;      // 64 or 128
+  bool fast;       // fp16 data with 16-byte row chunks: direct-to-LDS staging
+  int staging;     // flash_launch_info.staging
+  uint32_t lds;
+  uint32_t nqt;
+};
+
+// Shape / kernel-type checks shared by the launchers and the geometry query.  The error cases are
+// the reference's: head dim above the largest compiled tile (launch.cu:270-280), odd head dim for
+// mma_qreg (:267-269), head dim not a multiple of 4 for the vector-load and async kernels
+// (:284-286, :301-303), unknown kernel type (:317).
+int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool fp16_io, Plan* plan) {
+  if (kernel_type < 0 || kernel_type >= FLASH_KT_COUNT)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "Unsupported kernel type %d", kernel_type);
+  if (B <= 0 || H <= 0 || N <= 0 || d <= 0)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "B, H, N, d must be positive (got %lld, %lld, %lld, %lld)",
+                (long long)B, (long long)H, (long long)N, (long long)d);
+  if (kernel_type == FLASH_KT_MMA_QREG && d % 2 != 0)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "Head dim must be even for kernel %s", kNames[kernel_type]);
+  if ((kernel_type == FLASH_KT_MMA_QREG_F32X4LOAD || kernel_type == FLASH_KT_MMA_QREG_ASYNC) && d % 4 != 0)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "Head dim must be a multiple of 4 for kernel %s",
+                kNames[kernel_type]);
+  if (d > 128)
+    return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM,
+                "Unsupported tile size: head dim %lld exceeds the largest compiled tile (128) for kernel type: %s",
+                (long long)d, kNames[kernel_type]);
+  if (N * d * 4 >= (int64_t)kOob)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "one head (N*d = %lld elements) exceeds the 1 GiB descriptor range",
+                (long long)(N * d));
+  const int64_t nqt = (N + kBr - 1) / kBr;
+  if (B * H * nqt >= (int64_t)1 << 31)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "grid of %lld workgroups is too large", (long long)(B * H * nqt));
+  plan->tile_d = d <= 64 ? 64 : 128;
+  plan->fast = fp16_io && (d % 8 == 0);
+  plan->staging = plan->fast ? kStageDma : kStageElem;
+  plan->lds = plan->tile_d == 64 ? Geom<64>::kLdsBytes : Geom<128>::kLdsBytes;
+  plan->nqt = (uint32_t)nqt;
+  return FLASH_HIP_OK;
+}
+
+template <int D, typename T, bool FAST>
+int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
+  auto kern = attn_fwd_kernel<D, T, FAST>;
+  // Above the 64 KiB default a kernel must opt in to its dynamic LDS size (the reference does the
+  // same above 48 KiB, launch.cu:134-148).
+  static thread_local bool attr_done[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev < 16 && !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+      return fail(FLASH_HIP_ERR_LDS, "Failed to set dynamic shared memory size %u: %s", lds, hipGetErrorString(e));
+    attr_done[dev] = true;
+  }
+  static unsigned long long* dbg = nullptr;
+  static size_t dbg_n = 0;
+  FwdParams prm2 = prm;
+  const bool want = getenv("FLASH_DBG") != nullptr;
+  if (want) {
+    size_t n = (size_t)prm.total_wg * 4 * 8;
+    if (n > dbg_n) { (void)hipMalloc(&dbg, n * 8); dbg_n = n; }
+    prm2.dbg = dbg;
+  } else prm2.dbg = nullptr;
+  hipLaunchKernelGGL(kern, dim3(prm.total_wg), dim3(kThreads), lds, stream, prm2);
+  if (want) {
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned long long> h((size_t)prm.total_wg * 4 * 8);
+    (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    double a = 0, b = 0, c = 0, d2 = 0; unsigned long long tmin = ~0ull, tmax = 0;
+    for (size_t i = 0; i < (size_t)prm.total_wg * 4; ++i) {
+      const unsigned long long* t = &h[i * 8];
+      a += t[1] - t[0]; b += t[2] - t[1]; c += t[3] - t[2]; d2 += t[4] - t[3];
+      if (t[0] < tmin) tmin = t[0]; if (t[4] > tmax) tmax = t[4];
+    }
+    const double n = (double)prm.total_wg * 4;
+    printf("DBG phases (cycles, mean per wave): prologue %.0f  loop %.0f  finalPV+epilogue-issue %.0f  store-drain %.0f | kernel span %llu cycles, WGs per CU %.1f\n",
+           a / n, b / n, c / n, d2 / n, tmax - tmin, prm.total_wg / 256.0);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
+  return FLASH_HIP_OK;
+}
+
+template <typename T>
+int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+            float softmax_scale, int kernel_type, void* hip_stream) {
+  Plan plan;
+  int rc = make_plan(B, H, N, d, kernel_type, sizeof(T) == 2, &plan);
+  if (rc != FLASH_HIP_OK) return rc;
+  if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
+  FwdParams prm;
+  prm.q = q;
+  prm.k = k;
+  prm.v = v;
+  prm.o = o;
+  prm.N = (int)N;
+  prm.d = (int)d;
+  prm.nqt = (int)plan.nqt;
+  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
+  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if constexpr (sizeof(T) == 2) {
+    if (plan.fast) {
+      return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
+    }
+  }
+  return plan.tile_d == 64 ? launch<64, T, false>(prm, plan.lds, stream) : launch<128, T, false>(prm, plan.lds, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int flash_fwd_f16(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                  float softmax_scale, int kernel_type, void* hip_stream) {
+  return forward<f16>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
+}
+
+int flash_fwd_f32(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                  float softmax_scale, int kernel_type, void* hip_stream) {
+  return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
+}
+
+int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, flash_launch_info* out) {
+  if (!out) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null flash_launch_info");
+  Plan plan;
+  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
+  if (rc != FLASH_HIP_OK) return rc;
+  out->tile_kv = kBc;
+  out->tile_q = kBr;
+  out->tile_d = (uint32_t)plan.tile_d;
+  out->lds_bytes = plan.lds;
+  out->block_x = 64;
+  out->block_y = kWaves;
+  out->grid_x = (uint32_t)B;
+  out->grid_y = (uint32_t)H;
+  out->grid_z = plan.nqt;
+  out->staging = (uint32_t)plan.staging;
+  out->aligned_rows = (d % 8 == 0) ? 1u : 0u;
+  return FLASH_HIP_OK;
+}
+
+const char* flash_kernel_type_name(int kernel_type) {
+  if (kernel_type < 0 || kernel_type >= FLASH_KT_COUNT) return nullptr;
+  return kNames[kernel_type];
+}
+
+const char* flash_hip_last_error(void) { return g_err; }
+
+int flash_hip_version(void) { return 100; }
+
+}  // extern "C"

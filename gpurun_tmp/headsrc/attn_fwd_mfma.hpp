@@ -51,11 +51,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 #define FLASH_LDS_CAST(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-#ifndef FLASH_QB
-#define FLASH_QB 2
-#endif
-constexpr int kQB = FLASH_QB;               // 32-row query blocks per wave
-constexpr int kWaves = 8 / kQB;             // waves per workgroup: kQB = 2 -> one per SIMD, 1 -> two per SIMD
+constexpr int kWaves = 4;                   // waves per workgroup, one per SIMD
+constexpr int kQB = 2;                      // 32-row query blocks per wave
 constexpr int kRowsPerWave = 32 * kQB;      // 64 query rows per wave
 constexpr int kBr = kWaves * kRowsPerWave;  // 256 query rows per workgroup
 constexpr int kBc = 64;                     // key/value rows per LDS tile
@@ -166,12 +163,8 @@ __device__ __forceinline__ void mfma_o(f32x16& acc, const f16x8& a, const f16x8&
 // statement orders nothing, the compiler is free to move register reads across it.
 template <int NQ, int NB>
 __device__ __forceinline__ void mfma_drain_acc(f32x16 (&o)[NQ][NB]) {
-  static_assert((NQ == 1 || NQ == 2) && (NB == 2 || NB == 4), "operand list is written out for these shapes");
-  if constexpr (NQ == 1 && NB == 4) {
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]));
-  } else if constexpr (NQ == 1) {
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]));
-  } else if constexpr (NB == 4) {
+  static_assert(NQ == 2 && (NB == 2 || NB == 4), "operand list is written out for these shapes");
+  if constexpr (NB == 4) {
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]),
                    "+a"(o[1][2]), "+a"(o[1][3]));
@@ -182,7 +175,6 @@ __device__ __forceinline__ void mfma_drain_acc(f32x16 (&o)[NQ][NB]) {
 __device__ __forceinline__ void mfma_drain_s(f32x16 (&s)[2]) {
   asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
 }
-__device__ __forceinline__ void mfma_drain_s(f32x16 (&s)[1]) { asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0])); }
 
 // Raw buffer descriptor (stride 0, range-checked against `bytes`) as four wave-uniform dwords.
 typedef uint32_t srd_t __attribute__((ext_vector_type(4)));
@@ -305,46 +297,19 @@ __device__ __forceinline__ f16x8 read_k_frag(uint32_t koff, const LaneAddr<D>& l
 }
 
 // Running softmax state of one lane for one of its query blocks: the query is lane & 31 of that
-// block, the keys are those of the lane's half-wave.  Scores leave the MFMAs already multiplied by
-// softmax_scale * log2(e) (Q is pre-scaled) and RELATIVE to the reference `mc` (a rank-1 MFMA
-// k-step adds -mc to every key of the query), so the exponential reads the accumulator directly.
+// block, the keys are those of the lane's half-wave.
 struct SoftmaxState {
-  float mc;       // reference, in exp2 units, that S, P, l and O are relative to
+  float m;        // reference max (raw scores) that P, l and O are scaled against
+  float mc;       // m * c
   float l;        // this lane's partial row sum at that scale
   float alpha;    // factor still to be applied to O (valid while the wave's `pending` flag is set)
-  float mx_next;  // max of the next block's relative scores over this lane's keys
+  float mx_next;  // row max of the next block's scores (both half-waves)
 };
 
-// How far (in exp2 units) a score may exceed the reference before the state is moved to a new
-// reference.  P then stays below 2^kDeferLog2 = 256, far inside fp16 range, and O / l are fp32, so
-// the result is the same up to rounding; it saves the O-wide multiply on most blocks.
+// How far (in exp2 units, i.e. score * scale * log2 e) the row max may run ahead of `m` before the
+// state is rescaled.  P then stays below 2^kDeferLog2 = 256, far inside fp16 range, and O / l are
+// fp32, so the result is the same up to rounding; it saves the O-wide multiply on most blocks.
 constexpr float kDeferLog2 = 8.0f;
-
-// The reference is carried into the MFMA as two fp16 terms (hi + lo ~ 22 significant bits); the
-// value every other computation uses is the exact fp32 sum of the two.
-struct SplitRef {
-  f16 hi, lo;
-  float eff;
-};
-__device__ __forceinline__ SplitRef split_ref(float mc) {
-  SplitRef r;
-  r.hi = (f16)mc;
-  r.lo = (f16)(mc - (float)r.hi);
-  r.eff = (float)r.hi + (float)r.lo;
-  return r;
-}
-// B fragment of the rank-1 k-step: row k=0 holds -hi, row k=1 holds -lo of the lane's query (only
-// the lower half-wave owns k = 0..7), everything else is zero.  The matching A fragment is `ones`.
-__device__ __forceinline__ f16x8 bias_fragment(const SplitRef& r, int lane) {
-  f16x8 b;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) b[j] = (f16)0.f;
-  if (lane < 32) {
-    b[0] = -r.hi;
-    b[1] = -r.lo;
-  }
-  return b;
-}
 
 template <int D>
 __device__ __forceinline__ void rescale_o(f32x16 (&o)[Geom<D>::kDvBlocks], float alpha) {
@@ -374,122 +339,111 @@ __device__ __forceinline__ float block_row_max(const f32x16& s) {
   return fmaxf(mp.lo, mp.hi);
 }
 
-// One pipeline step.  With one wave per SIMD the step is bound by instruction ISSUE, not by the
-// matrix pipe: every non-MFMA instruction costs 4-9 issue cycles (v_exp_f32 9, v_cvt_pk_f16_f32 8,
-// an LDS read 7.5, simple VALU 5) against 32 cycles of matrix pipe per MFMA, so the step carries the
-// minimum of them: per score one v_exp_f32, half a v_cvt_pk_f16_f32, a quarter each of v_pk_add_f16
-// and v_dot2c_f32_f16 (row sum of the rounded probabilities, fp32 accumulation) and half a
-// v_max3_f32.  The instruction order below is the intended issue order: the step is cut into SLOTS of
-// one MFMA each, and a scheduling fence after each slot keeps the compiler from regrouping them
-// (left alone it hoists every LDS read to the top of the step and spills).
-//   QK slots ((KS+1) * kQB)  QK(j+1): s_nxt[q] = ones * bias[q] (rank-1: -reference), then
-//                            += K_{j+1}[ks] * Q[q][ks]; the K fragment register just consumed by both
-//                            query blocks is refilled (rest of this block, then the first fragments
-//                            of block j+2)
-//   PV slots (2*NB * kQB)    PV(j-1): O^T[q][b] += V_{j-1}^T[b] * P_{j-1}[q]^T, V fragments two dv
-//                            blocks ahead; in-lane max of s_nxt once the QK chain has drained
-//   all slots                exp(j): a share of p_cur = exp2(s_cur) and of the row sum
+// One pipeline step.  The instruction order below is the intended issue order: the step is cut into
+// SLOTS of one MFMA each, and every slot also carries the LDS reads and the few vector instructions
+// that should issue in the shadow of that MFMA (one v_exp per slot at D = 128); a scheduling fence
+// after each slot keeps the compiler from regrouping them (left alone it hoists every LDS read to
+// the top of the step and spills).
+//   QK slots (KS * kQB)    QK(j+1): s_nxt[q] += K_{j+1}[ks] * Q[q][ks]; the K fragment register just
+//                          consumed by both query blocks is refilled (rest of this block, then the
+//                          first fragments of block j+2)
+//   PV slots (2*NB * kQB)  PV(j-1): O^T[q][b] += V_{j-1}^T[b] * P_{j-1}[q]^T, V fragments two dv blocks
+//                          ahead; row max of s_nxt once the QK chain has drained
+//   all slots              exp(j): a share of p_cur = exp2(s_cur*c - m*c) and of the row sum
 template <int D, bool PAD, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, typename Hook>
 __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uint32_t vb, uint32_t kb_next,
-                                              const LaneAddr<D>& la, const f16x8& ones,
-                                              const f16x8 (&bq)[kQB], const f16x8 (&qf)[kQB][Geom<D>::kKSteps],
-                                              f16x8 (&ka)[Geom<D>::kKHold], f32x16 (&o)[kQB][Geom<D>::kDvBlocks],
-                                              const f32x16 (&s_cur)[kQB], f32x16 (&s_nxt)[kQB],
-                                              const f16x8 (&p_prev)[kQB][2], f16x8 (&p_cur)[kQB][2],
-                                              SoftmaxState (&st)[kQB], int kv_next0, int N, int lane) {
+                                              const LaneAddr<D>& la,
+                                              const f16x8 (&qf)[kQB][Geom<D>::kKSteps], f16x8 (&ka)[Geom<D>::kKHold],
+                                              f32x16 (&o)[kQB][Geom<D>::kDvBlocks], const f32x16 (&s_cur)[kQB],
+                                              f32x16 (&s_nxt)[kQB], const f16x8 (&p_prev)[kQB][2],
+                                              f16x8 (&p_cur)[kQB][2], SoftmaxState (&st)[kQB], float c, int kv_next0,
+                                              int N, int lane) {
   using G = Geom<D>;
   constexpr int KS = G::kKSteps;
   constexpr int KH = G::kKHold;
   constexpr int NB = G::kDvBlocks;
-  constexpr int QK_SLOTS = (KS + 1) * kQB;
+  constexpr int QK_SLOTS = KS * kQB;
   constexpr int PV_SLOTS = 2 * NB * kQB;
   constexpr int SLOTS = QK_SLOTS + PV_SLOTS;
-  constexpr int ELEMS = 16 * kQB;        // scores per lane and step
-  constexpr int MAX_OPS = 8 * kQB;       // in-lane max micro-ops: 8 per query block (16 registers)
+  constexpr int EPS = 16 * kQB / SLOTS;  // exp elements per slot (1 for D=128, 2 for D=64)
+  static_assert(EPS * SLOTS == 16 * kQB, "exp elements must divide evenly over the slots");
+  constexpr int MAX_OPS = 5 * kQB;       // row-max micro-ops: 4 four-register chunks + 1 cross-half per block
   constexpr int MAX_DELAY = 2;           // PV slots to wait for the QK chain to drain
 
   f16x8 va[4];
+  float rs[kQB];
+  float nmc[kQB];
   float mx[kQB];
 #pragma unroll
-  for (int q = 0; q < kQB; ++q) mx[q] = 0.f;
+  for (int q = 0; q < kQB; ++q) {
+    rs[q] = 0.f;
+    nmc[q] = -st[q].mc;
+    mx[q] = 0.f;
+  }
 
-  // exp(j) share, software-pipelined over the slots so that no instruction consumes a result
-  // produced right before it (a lone wave has nothing else to issue while it waits).  After the
-  // exponential of element g:
-  //   g odd        pack (g-1, g) to fp16: one register of the P^T fragment
-  //   g % 4 == 0   fp16 sum of the two pairs of the group of four before (2-term sums: the error
-  //                stays at fp16 rounding of the result, a longer fp16 chain would drop small terms)
-  //   g % 4 == 2   that group's two sums into the fp32 row sum (v_dot2c_f32_f16 with ones)
+  // exp(j) share of slot n, software-pipelined over the slots so that no instruction consumes a
+  // result produced in the same slot (a lone wave has nothing else to issue while it waits for one):
+  //   element g+1: a = s*c - m*c        element g: x = exp2(a from the slot before)
+  //   element g-1: row sum += x, and once both halves of a pair exist: pack to fp16
+  // g = n*EPS + e runs over the 16*kQB elements of the wave's query blocks (block g/16).
+  float t_arg = __builtin_fmaf(s_cur[0][0], c, nmc[0]);  // element 0
   float t_exp = 0.f, t_exp_prev = 0.f;
-  f16x2 pk[2], ps, one2;
-  one2[0] = one2[1] = (f16)1.f;
-  // keeps the instruction that produced x in the slot it was written in
-  auto pin = [](f16x2& x) __attribute__((always_inline)) {
-    uint32_t w = __builtin_bit_cast(uint32_t, x);
-    asm volatile("" : "+v"(w));
-    x = __builtin_bit_cast(f16x2, w);
-  };
-  auto group_sum = [&]() __attribute__((always_inline)) {
-    ps = pk[0] + pk[1];
-    pin(ps);
-  };
-  auto group_add = [&](int group) __attribute__((always_inline)) {
-    float& l = st[group / 4].l;
-    l = __builtin_amdgcn_fdot2(ps, one2, l, false);
-    asm volatile("" : "+v"(l));
-  };
-  auto finish = [&](int g) __attribute__((always_inline)) {  // element g has its exponential
+  auto finish = [&](int g) __attribute__((always_inline)) {  // element g: sum and (odd g) pack
     const int q = g / 16, i = g % 16;
-    if ((g & 3) == 0 && g >= 4) group_sum();
-    if ((g & 3) == 2 && g >= 6) group_add(g / 4 - 1);
-    if ((g & 1) != 0) {
-      f16x2 w;
-      w[0] = (f16)t_exp_prev;
-      w[1] = (f16)t_exp;
-      pin(w);  // otherwise the fp32 exponentials stay alive and are converted several slots later
-      p_cur[q][i >> 3][(i & 7) - 1] = w[0];
-      p_cur[q][i >> 3][i & 7] = w[1];
-      pk[(g >> 1) & 1] = w;
+    rs[q] += t_exp;
+    if ((i & 1) != 0) {
+      f16x2 pk;
+      pk[0] = (f16)t_exp_prev;
+      pk[1] = (f16)t_exp;
+      // pin the packed pair and the running sum here: otherwise the compiler keeps the fp32
+      // exponentials alive and converts / adds them several slots later
+      uint32_t w = __builtin_bit_cast(uint32_t, pk);
+      asm volatile("" : "+v"(w), "+v"(rs[q]));
+      pk = __builtin_bit_cast(f16x2, w);
+      p_cur[q][i >> 3][(i & 7) - 1] = pk[0];
+      p_cur[q][i >> 3][i & 7] = pk[1];
     }
     t_exp_prev = t_exp;
   };
   auto exp_share = [&](int n) __attribute__((always_inline)) {
 #pragma unroll
-    for (int g = n * ELEMS / SLOTS; g < (n + 1) * ELEMS / SLOTS; ++g) {
+    for (int e = 0; e < EPS; ++e) {
+      const int g = n * EPS + e;
       if (g > 0) finish(g - 1);
-      t_exp = fast_exp2(s_cur[g / 16][g % 16]);
-      asm volatile("" : "+v"(t_exp));
+      t_exp = fast_exp2(t_arg);
+      if (g + 1 < 16 * kQB) t_arg = __builtin_fmaf(s_cur[(g + 1) / 16][(g + 1) % 16], c, nmc[(g + 1) / 16]);
     }
   };
-  // in-lane max micro-op u of s_nxt: query block u / 8, op u % 8 folds two more registers
+  // row-max micro-op u (0 .. MAX_OPS-1) of s_nxt: chunk u%5 < 4 folds registers 4c..4c+3, u%5 == 4
+  // combines the two half-waves
   auto max_op = [&](int u) __attribute__((always_inline)) {
-    const int q = u / 8, k = u % 8;
-    if (k == 0) {
+    const int q = u / 5, cidx = u % 5;
+    if (cidx == 0) {
       if constexpr (MASKED) mask_scores(s_nxt[q], kv_next0, N, lane);
-      mx[q] = fmaxf(fmaxf(s_nxt[q][0], s_nxt[q][1]), s_nxt[q][2]);
-    } else if (k < 7) {
-      mx[q] = fmaxf(fmaxf(mx[q], s_nxt[q][2 * k + 1]), s_nxt[q][2 * k + 2]);
+      mx[q] = fmaxf(fmaxf(s_nxt[q][0], s_nxt[q][1]), fmaxf(s_nxt[q][2], s_nxt[q][3]));
+    } else if (cidx < 4) {
+      mx[q] = fmaxf(mx[q], fmaxf(fmaxf(s_nxt[q][4 * cidx], s_nxt[q][4 * cidx + 1]),
+                                 fmaxf(s_nxt[q][4 * cidx + 2], s_nxt[q][4 * cidx + 3])));
     } else {
-      mx[q] = fmaxf(mx[q], s_nxt[q][15]);
-      st[q].mx_next = mx[q];
+      const HalfPair mp = both_halves(mx[q]);
+      st[q].mx_next = fmaxf(mp.lo, mp.hi);
     }
-    asm volatile("" : "+v"(mx[q]));  // keep the op in this slot
   };
 
   // ---- QK slots ------------------------------------------------------------------------------------
 #pragma unroll
-  for (int ks = -1; ks < KS; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int q = 0; q < kQB; ++q) {
-      const int n = (ks + 1) * kQB + q;
+      const int n = ks * kQB + q;
       if constexpr (HAS_QK) {
-        if (ks < 0) {
-          mfma_s_first<PAD>(s_nxt[q], ones, bq[q]);
+        if (ks == 0) {
+          mfma_s_first<PAD>(s_nxt[q], ka[ks % KH], qf[q][ks]);
         } else {
           mfma_s<PAD>(s_nxt[q], ka[ks % KH], qf[q][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);  // the MFMA opens its slot, the fillers follow it
-        if (ks >= 0 && q == kQB - 1) {
+        if (q == kQB - 1) {
           if (ks + KH < KS) {
             ka[ks % KH] = read_k_frag<D>(kb, la, ks + KH);
           } else if constexpr (HAS_PRELOAD) {
@@ -498,11 +452,11 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uin
         }
       }
       // V fragments of the first two dv blocks, a few slots before the PV slots begin
-      if (n == (QK_SLOTS >= 6 ? QK_SLOTS - 6 : 0)) {
+      if (n == QK_SLOTS - 6 || (QK_SLOTS < 6 && n == 0)) {
         va[0] = read_v_frag<D>(vb, la, 0, 0);
         va[1] = read_v_frag<D>(vb, la, 0, 1);
       }
-      if (n == (QK_SLOTS >= 6 ? QK_SLOTS - 4 : 1)) {
+      if (n == QK_SLOTS - 4 || (QK_SLOTS < 6 && n == 1)) {
         va[2] = read_v_frag<D>(vb, la, 1, 0);
         va[3] = read_v_frag<D>(vb, la, 1, 1);
       }
@@ -535,27 +489,21 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uin
       }
     }
   }
-  finish(ELEMS - 1);
-  group_sum();
-  group_add(ELEMS / 4 - 1);
+  finish(16 * kQB - 1);
+#pragma unroll
+  for (int q = 0; q < kQB; ++q) st[q].l += rs[q];
 }
 
 // Between two steps: apply a pending O rescale (the P V product it had to wait for has been issued),
-// then decide whether the block whose in-lane maxima are st.mx_next forces a new reference.  Both are
-// rare, wave-uniform events; the common path is one vector compare and one scalar branch.
-// Moving the reference by d: the scores of the next block, already computed against the old one,
-// drop by d; l and (one step later, once the P V product of the current block is in) O shrink by
-// 2^-d; the bias fragment of the rank-1 k-step is rebuilt.
-template <int D, bool HAS_NEXT>
-__device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], SoftmaxState (&st)[kQB],
-                                         f16x8 (&bq)[kQB], f32x16 (&s_nxt)[kQB], bool& pending, int lane) {
-  bool any_need = false;
-  if constexpr (HAS_NEXT) {
-    float mxx = st[0].mx_next;
+// then decide whether the block whose row max is st.mx_next forces a new reference max.  Both are
+// rare, wave-uniform events; the common path is one scalar test.
+template <int D>
+__device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], SoftmaxState (&st)[kQB], bool& pending,
+                                         float c, bool has_next) {
+  bool need = false;
 #pragma unroll
-    for (int q = 1; q < kQB; ++q) mxx = fmaxf(mxx, st[q].mx_next);
-    any_need = __builtin_amdgcn_ballot_w64(mxx > kDeferLog2) != 0;
-  }
+  for (int q = 0; q < kQB; ++q) need = need || ((st[q].mx_next - st[q].m) * c > kDeferLog2);
+  const bool any_need = has_next && (__builtin_amdgcn_ballot_w64(need) != 0);
   if (__builtin_expect(pending || any_need, 0)) {  // rare: keep it out of the fall-through path
     if (pending) {
       mfma_drain_acc(o);  // the last P V MFMAs of the step must have written O
@@ -566,22 +514,11 @@ __device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], S
     if (any_need) {
 #pragma unroll
       for (int q = 0; q < kQB; ++q) {
-        const HalfPair mp = both_halves(st[q].mx_next);
-        const float rise = fmaxf(fmaxf(mp.lo, mp.hi), 0.f);  // references only move up
-        const SplitRef r = split_ref(st[q].mc + rise);
-        const float d = r.eff - st[q].mc;
-        st[q].alpha = fast_exp2(-d);  // 1 for rows whose reference does not move
-        st[q].mc = r.eff;
+        const float m_new = fmaxf(st[q].m, st[q].mx_next);
+        st[q].alpha = fast_exp2((st[q].m - m_new) * c);  // 1 for rows whose reference does not move
+        st[q].m = m_new;
+        st[q].mc = m_new * c;
         st[q].l *= st[q].alpha;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s_nxt[q][i] -= d;
-        bq[q] = bias_fragment(r, lane);
-      }
-      // the rebuilt fragments are MFMA operands of the very next instruction group
-      if constexpr (kQB == 2) {
-        asm volatile("s_nop 4" : "+a"(bq[0]), "+a"(bq[kQB - 1]));
-      } else {
-        asm volatile("s_nop 4" : "+a"(bq[0]));
       }
       pending = true;
     }
@@ -719,14 +656,12 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
         const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * 2u : kOob;
         const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
         qf[q][ks] = __builtin_bit_cast(f16x8, raw);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const uint32_t off =
               (col + j < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)(col + j)) * (uint32_t)sizeof(T) : kOob;
-          qf[q][ks][j] = (f16)((float)load_elem<T>(q_rs, off) * p.scale_log2e);
+          qf[q][ks][j] = load_elem<T>(q_rs, off);
         }
       }
     }
@@ -745,6 +680,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
       asm volatile("" : "+a"(o[q][b]));
     }
   }
+  const float c = p.scale_log2e;
   const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
 
   staged_barrier();
@@ -780,26 +716,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     }
   }
   mfma_drain_s(sA);
-  // The first reference of every query is the row max of block 0 (which always holds key 0, so it
-  // is finite); S(0) was computed without a bias, make it relative now.
   SoftmaxState st[kQB];
-  f16x8 bq[kQB];
-  f16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (f16)((lane < 32 && j < 2) ? 1.f : 0.f);
   bool pending = false;
 #pragma unroll
   for (int q = 0; q < kQB; ++q) {
     mask_scores(sA[q], 0, N, lane);
-    const SplitRef r = split_ref(block_row_max(sA[q]));
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sA[q][i] -= r.eff;
-    bq[q] = bias_fragment(r, lane);
-    asm volatile("" : "+a"(bq[q]));
-    st[q].mc = r.eff;
+    st[q].m = block_row_max(sA[q]);  // block 0 always holds key 0, so this is finite
+    st[q].mc = st[q].m * c;
     st[q].l = 0.f;
     st[q].alpha = 1.f;
-    st[q].mx_next = 0.f;
+    st[q].mx_next = st[q].m;
   }
 
   // One tile iteration.  SLOT >= 0: ring slot of tile t known at compile time (all LDS offsets
@@ -815,13 +741,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     // staging spread over the slots of the first step: piece i of the wave at slot i * spacing + 1
     auto dma_hook = [&](int n) __attribute__((always_inline)) {
       if constexpr (FAST) {
-        constexpr int kSlotsPerStep = (G::kKSteps + 1) * kQB + 2 * G::kDvBlocks * kQB;
+        constexpr int kSlotsPerStep = G::kKSteps * kQB + 2 * G::kDvBlocks * kQB;
         constexpr int kSpacing = kSlotsPerStep / (2 * G::kPiecesPerWave);
         if (n % kSpacing == 1) {
           const int i = n / kSpacing;
-          if (i >= 2 * G::kPiecesPerWave) {
-            // no piece left for this slot
-          } else if (i < G::kPiecesPerWave) {
+          if (i < G::kPiecesPerWave) {
             if (t + 2 < nt) {
               const int pc = wave * G::kPiecesPerWave + i;
               const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(k_ring + s2 * G::kTileBytes + pc * 1024));
@@ -846,12 +770,12 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     const uint32_t k_nxt = (uint32_t)(s1 * G::kTileBytes);
     const uint32_t v_cur = (uint32_t)(s0 * G::kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * G::kTileBytes);
-    pipeline_step<D, !FAST, true, !LAST, MASKED>(dma_hook, k_cur + kBlk, v_prv + kBlk, k_nxt, la, ones, bq, qf, ka, o, sA,
-                                                 sB, pB, pA, st, t * kBc + 32, N, lane);
-    step_end<D, true>(o, st, bq, sB, pending, lane);
-    pipeline_step<D, !FAST, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlk, la, ones, bq, qf, ka, o, sB, sA, pA,
-                                                  pB, st, (t + 1) * kBc, N, lane);
-    step_end<D, !LAST>(o, st, bq, sA, pending, lane);
+    pipeline_step<D, !FAST, true, !LAST, MASKED>(dma_hook, k_cur + kBlk, v_prv + kBlk, k_nxt, la, qf, ka, o, sA, sB, pB, pA, st, c,
+                                          t * kBc + 32, N, lane);
+    step_end<D>(o, st, pending, c, true);
+    pipeline_step<D, !FAST, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlk, la, qf, ka, o, sB, sA, pA, pB, st, c,
+                                           (t + 1) * kBc, N, lane);
+    step_end<D>(o, st, pending, c, !LAST);
     staged_barrier();
   };
   using std::integral_constant;
