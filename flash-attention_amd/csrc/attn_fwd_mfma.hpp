@@ -885,23 +885,42 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     mfma_drain_acc(o);
   }
 
-  // ---- epilogue: O = O^T / l, registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 ----------
+  // ---- epilogue: O = O^T / l ----------------------------------------------------------------------
+  // Registers 4g..4g+3 of block b are dv = 32b + 8g + 4h + 0..3 of the lane's query row.  The two
+  // half-waves trade their 4-column groups (v_permlane32_swap) so that a lane owns 8 consecutive
+  // columns and writes them with one 128-bit store: the lower half-wave takes columns 0..7 of each
+  // 16-column group, the upper half-wave columns 8..15.
 #pragma unroll
   for (int q = 0; q < kQB; ++q) {
     const HalfPair lp = both_halves(st[q].l);
     const float inv = 1.0f / (lp.lo + lp.hi);
 #pragma unroll
     for (int b = 0; b < G::kDvBlocks; ++b) {
+      if constexpr (FAST) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int dv = 32 * b + 8 * g + 4 * h;
-        if constexpr (FAST) {
-          f16x4 pk;
+        for (int gp = 0; gp < 2; ++gp) {
+          f16x4 x, y;  // groups 2gp and 2gp+1
 #pragma unroll
-          for (int j = 0; j < 4; ++j) pk[j] = (f16)(o[q][b][4 * g + j] * inv);
+          for (int j = 0; j < 4; ++j) {
+            x[j] = (f16)(o[q][b][8 * gp + j] * inv);
+            y[j] = (f16)(o[q][b][8 * gp + 4 + j] * inv);
+          }
+          const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+          u32x4 out;
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {
+            auto r = __builtin_amdgcn_permlane32_swap(xu[w], yu[w], false, false);
+            out[w] = r[0];      // lower lanes: own group 2gp      upper lanes: partner's group 2gp+1
+            out[2 + w] = r[1];  // lower lanes: partner's group 2gp upper lanes: own group 2gp+1
+          }
+          const int dv = 32 * b + 16 * gp + 8 * h;
           const uint32_t off = (dv < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), o_rs, off, 0, 0);
-        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dv = 32 * b + 8 * g + 4 * h;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const uint32_t off = (dv + j < d)
