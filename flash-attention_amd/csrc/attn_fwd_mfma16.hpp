@@ -1,0 +1,592 @@
+// FlashAttention-2 forward for gfx950, head-dim tile 128, fp16 rows of a multiple of 8 elements,
+// built on v_mfma_f32_16x16x32_f16.
+//
+// Same structure as attn_fwd_mfma.hpp (4 waves, one per SIMD, 64 query rows each; transposed
+// products S^T = K Q^T and O^T = V^T P^T so that a lane owns one query column; K/V in 3-slot LDS
+// rings filled by global->LDS DMA; software pipeline over 32-key blocks with a deferred reference
+// update), but with the 16x16x32 MFMA shape instead of 32x32x16.  Under dense MFMA load the chip
+// holds a clock well below nominal and the achieved rate is set by energy per MFMA, not by issue
+// cycles; the 16x16x32 shape moves half as many accumulator registers per FLOP and sustains a
+// visibly higher FLOP rate at the same power (tools/microbench/mfma_clock.cpp).  Its 4-register
+// accumulator tiles also make the softmax reference cheap to carry: the first k-step of every score
+// tile takes the per-query constant -reference as its srcC operand (four VGPRs per query block), so
+// no rank-1 MFMA and no per-score subtraction is needed.
+//
+// Fragment maps (lane l: n = l & 15, g = l >> 4):
+//   A (16 x 32): row n, k = 8g + j.   B (32 x 16): k = 8g + j, column n.   C/D: column n, rows 4g + i.
+//   S^T tile (16 keys x 16 queries), k-step ks: A = K[key n][chunk ks + 4g] (one ds_read_b128; the
+//     chunk permutation makes the read conflict-free), B = Q[query n][chunk ks + 4g] from AGPRs.
+//     The lane ends up with keys 4g + i of key block kb for its query.
+//   P^T fragment of a 32-key block: element j < 4 is key 4g + j of key block 0, j >= 4 key 4g + j - 4
+//     of key block 1: exactly the two S^T tiles of the block converted to fp16, no lane movement.
+//   O^T tile (16 dv x 16 queries): A = V^T with the same key order: two ds_read_b64_tr_b16 (keys
+//     4g.. of rows 0..15 and of rows 16..31 of the block), B = P^T fragment, K = all 32 keys.
+#pragma once
+#include "attn_fwd_mfma.hpp"
+
+namespace flash_hip {
+namespace m16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 128;
+constexpr int kQ16 = 4;                       // 16-row query blocks per wave
+constexpr int kDv16 = kD / 16;                // 16-row blocks of O^T
+constexpr int kKS = kD / 32;                  // k-steps of a score tile
+constexpr int kRowBytes = kD * 2;
+constexpr int kTileBytes = kBc * kRowBytes;   // 16 KiB
+constexpr int kRing = 3;
+constexpr int kLdsBytes = 2 * kRing * kTileBytes;
+constexpr int kPiecesPerWave = kTileBytes / 1024 / 4;
+constexpr int kBlkBytes = 32 * kRowBytes;     // one 32-key block
+static_assert(kWaves == 4 && kRowsPerWave == 64, "written for one wave per SIMD with 64 query rows");
+
+// 16-byte-chunk XOR swizzle of a 256-byte LDS row, f(row) = 2*(row & 7) | bit 3 of row:
+//  - ds_read_b128 of chunk ks + 4g of rows 0..15 (K operand): every 16-lane service group of the
+//    instruction touches 16 different 16-byte slots;
+//  - ds_read_b64_tr_b16 of 32 bytes of each of rows 4g..4g+3 (V operand): the 8 rows of a half-wave
+//    land on 8 different 32-byte slot pairs.
+__device__ __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ swz(row)) << 4); }
+
+// S^T tile: first k-step takes srcC from `c0` (the bias registers or 0), later ones accumulate.
+__device__ __forceinline__ void mfma_s_first(f32x4& acc, const f16x8& a, const f16x8& b, const f32x4& c0) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c0));
+}
+__device__ __forceinline__ void mfma_s_first0(f32x4& acc, const f16x8& a, const f16x8& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+}
+template <bool PAD>
+__device__ __forceinline__ void mfma_s(f32x4& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (PAD) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  } else {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  }
+}
+template <bool PAD>
+__device__ __forceinline__ void mfma_o(f32x4& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (PAD) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  } else {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  }
+}
+
+// Wait states for the last MFMAs, with the accumulators as operands so that their readers stay
+// behind the wait.  The statements are volatile, hence ordered among themselves: the first one
+// carries the wait, the others only tie the remaining registers to that order.
+__device__ __forceinline__ void drain_o(f32x4 (&o)[kQ16][kDv16]) {
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+    asm volatile("" : "+a"(o[q][0]), "+a"(o[q][1]), "+a"(o[q][2]), "+a"(o[q][3]), "+a"(o[q][4]), "+a"(o[q][5]),
+                 "+a"(o[q][6]), "+a"(o[q][7]));
+  }
+}
+__device__ __forceinline__ void drain_s(f32x4 (&s)[2][kQ16]) {
+  asm volatile("s_nop 15\n\ts_nop 15"
+               : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]),
+                 "+v"(s[1][2]), "+v"(s[1][3]));
+}
+
+// max / sum over the four lanes (g = 0..3) that share a query column.  Only used on rare paths.
+__device__ __forceinline__ float quad_lane_max(float x, int lane) {
+  float y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_uint(x)));
+  x = fmaxf(x, y);
+  y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_uint(x)));
+  return fmaxf(x, y);
+}
+__device__ __forceinline__ float quad_lane_sum(float x, int lane) {
+  float y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_uint(x)));
+  x += y;
+  y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_uint(x)));
+  return x + y;
+}
+
+struct LaneAddr {
+  uint32_t k[kKS];    // K[row n][chunk ks + 4g] of slot 0 / row block 0
+  uint32_t v[kDv16];  // V rows 4g + (i16 >> 2), 8-byte piece (i16 & 3) of dv block b
+};
+
+__device__ __forceinline__ LaneAddr make_lane_addr(int lane, lds_char* k_ring, lds_char* v_ring) {
+  LaneAddr la;
+  const int n = lane & 15, g = lane >> 4;
+  const int tq = n >> 2, tp = n & 3;
+  const uint32_t kbase = (uint32_t)(uintptr_t)k_ring, vbase = (uint32_t)(uintptr_t)v_ring;
+#pragma unroll
+  for (int ks = 0; ks < kKS; ++ks) {
+    uint32_t a = kbase + (uint32_t)lds_off(n, ks + 4 * g);
+    asm volatile("" : "+v"(a));
+    la.k[ks] = a;
+  }
+#pragma unroll
+  for (int b = 0; b < kDv16; ++b) {
+    uint32_t a = vbase + (uint32_t)(lds_off(4 * g + tq, 2 * b + (tp >> 1)) + 8 * (tp & 1));
+    asm volatile("" : "+v"(a));
+    la.v[b] = a;
+  }
+  return la;
+}
+
+// K fragment: 16-row block rb (0..3 inside a 64-row tile) of the tile that starts `koff` bytes into the ring.
+__device__ __forceinline__ f16x8 read_k(uint32_t koff, const LaneAddr& la, int rb, int ks) {
+  return *(FLASH_LDS_CAST(f16x8, (uintptr_t)(la.k[ks] + koff + (uint32_t)(rb * 16 * kRowBytes))));
+}
+// V^T fragment of dv block b for the 32-key block that starts `voff` bytes into the ring.
+__device__ __forceinline__ f16x8 read_v(uint32_t voff, const LaneAddr& la, int b) {
+  f16x8 a;
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const uint32_t addr = la.v[b] + voff + (uint32_t)(jj * 16 * kRowBytes);
+    const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(FLASH_LDS_CAST(fp16x4_b, (uintptr_t)addr));
+    const f16x4 tv = __builtin_bit_cast(f16x4, t);
+    a[4 * jj + 0] = tv[0];
+    a[4 * jj + 1] = tv[1];
+    a[4 * jj + 2] = tv[2];
+    a[4 * jj + 3] = tv[3];
+  }
+  return a;
+}
+
+struct State {
+  float mc;       // reference, exp2 units, of the lane's query in this query block
+  float l;        // partial row sum over this lane's keys
+  float alpha;    // pending O factor
+  float mx_next;  // max of the next block's relative scores over this lane's keys
+};
+
+// Register i of S^T tile kb holds key kv0 + 16*kb + 4*g + i.
+__device__ __forceinline__ void mask_tile(f32x4& s, int kv_tile0, int N, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (kv_tile0 + 4 * g + i >= N) s[i] = -INFINITY;
+  }
+}
+
+// One pipeline step: QK(j+1) (32 MFMAs), PV(j-1) (32 MFMAs), exp(j), in-lane max(j+1).
+//   s_cur/s_nxt[kb][q]: S^T tiles of key block kb (16 keys) and query block q (16 queries)
+//   p_prev/p_cur[q]:    P^T fragments (32 keys) of query block q
+template <bool HAS_QK, bool HAS_PRELOAD, bool MASKED, typename Hook>
+__device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off, uint32_t vb_off, uint32_t kb_next_off,
+                                              const LaneAddr& la, const f32x4 (&bias)[kQ16],
+                                              const f16x8 (&qf)[kQ16][kKS], f16x8 (&ka)[4],
+                                              f32x4 (&o)[kQ16][kDv16], const f32x4 (&s_cur)[2][kQ16],
+                                              f32x4 (&s_nxt)[2][kQ16], const f16x8 (&p_prev)[kQ16],
+                                              f16x8 (&p_cur)[kQ16], State (&st)[kQ16], int kv_next0, int N, int lane) {
+  constexpr int QK_SLOTS = 2 * kKS * kQ16;  // 32
+  constexpr int PV_SLOTS = kDv16 * kQ16;    // 32
+  constexpr int SLOTS = QK_SLOTS + PV_SLOTS;
+  constexpr int ELEMS = 8 * kQ16;           // scores per lane and step
+  constexpr int MAX_OPS = 4 * kQ16;
+  constexpr int MAX_DELAY = 2;
+
+  f16x8 va[4];
+  float mx[kQ16];
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) mx[q] = 0.f;
+
+  // exp(j), software-pipelined over the slots.  Element g = 8q + e: key block e / 4, register e % 4.
+  float t_exp = 0.f, t_exp_prev = 0.f;
+  f16x2 pk[2], ps, one2;
+  one2[0] = one2[1] = (f16)1.f;
+  auto pin = [](f16x2& x) __attribute__((always_inline)) {
+    uint32_t w = __builtin_bit_cast(uint32_t, x);
+    asm volatile("" : "+v"(w));
+    x = __builtin_bit_cast(f16x2, w);
+  };
+  auto group_sum = [&]() __attribute__((always_inline)) {
+    ps = pk[0] + pk[1];
+    pin(ps);
+  };
+  auto group_add = [&](int group) __attribute__((always_inline)) {
+    float& l = st[group / 2].l;
+    l = __builtin_amdgcn_fdot2(ps, one2, l, false);
+    asm volatile("" : "+v"(l));
+  };
+  auto finish = [&](int g) __attribute__((always_inline)) {
+    const int q = g / 8, e = g % 8;
+    if ((g & 3) == 0 && g >= 4) group_sum();
+    if ((g & 3) == 2 && g >= 6) group_add(g / 4 - 1);
+    if ((g & 1) != 0) {
+      f16x2 w;
+      w[0] = (f16)t_exp_prev;
+      w[1] = (f16)t_exp;
+      pin(w);
+      p_cur[q][e - 1] = w[0];
+      p_cur[q][e] = w[1];
+      pk[(g >> 1) & 1] = w;
+    }
+    t_exp_prev = t_exp;
+  };
+  auto exp_share = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = n * ELEMS / SLOTS; g < (n + 1) * ELEMS / SLOTS; ++g) {
+      if (g > 0) finish(g - 1);
+      t_exp = fast_exp2(s_cur[(g % 8) / 4][g / 8][g % 4]);
+      asm volatile("" : "+v"(t_exp));
+    }
+  };
+  // in-lane max micro-op u of s_nxt: query block u / 4; the 8 values are tile 0 regs 0..3, tile 1 regs 0..3
+  auto max_op = [&](int u) __attribute__((always_inline)) {
+    const int q = u / 4, k = u % 4;
+    const f32x4& t0 = s_nxt[0][q];
+    const f32x4& t1 = s_nxt[1][q];
+    if (k == 0) {
+      if constexpr (MASKED) {
+        mask_tile(s_nxt[0][q], kv_next0, N, lane);
+        mask_tile(s_nxt[1][q], kv_next0 + 16, N, lane);
+      }
+      mx[q] = fmaxf(fmaxf(t0[0], t0[1]), t0[2]);
+    } else if (k == 1) {
+      mx[q] = fmaxf(fmaxf(mx[q], t0[3]), t1[0]);
+    } else if (k == 2) {
+      mx[q] = fmaxf(fmaxf(mx[q], t1[1]), t1[2]);
+    } else {
+      mx[q] = fmaxf(mx[q], t1[3]);
+      st[q].mx_next = mx[q];
+    }
+    asm volatile("" : "+v"(mx[q]));
+  };
+
+  // ---- QK slots: key block kb, k-step ks, query block q; K fragment index f = 4 kb + ks -------------
+#pragma unroll
+  for (int f = 0; f < 2 * kKS; ++f) {
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+      const int n = f * kQ16 + q;
+      const int kb = f / kKS, ks = f % kKS;
+      if constexpr (HAS_QK) {
+        if (ks == 0) {
+          mfma_s_first(s_nxt[kb][q], ka[f % 4], qf[q][ks], bias[q]);
+        } else {
+          mfma_s<false>(s_nxt[kb][q], ka[f % 4], qf[q][ks]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (q == kQ16 - 1) {
+          if (f + 4 < 2 * kKS) {
+            ka[f % 4] = read_k(kb_off, la, (f + 4) / kKS, (f + 4) % kKS);
+          } else if constexpr (HAS_PRELOAD) {
+            ka[f % 4] = read_k(kb_next_off, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
+          }
+        }
+      }
+      // the first four V^T fragments, shortly before the PV slots begin
+      if (n >= QK_SLOTS - 10 && n < QK_SLOTS - 2 && ((n - (QK_SLOTS - 10)) & 1) == 0) {
+        const int b = (n - (QK_SLOTS - 10)) / 2;
+        va[b] = read_v(vb_off, la, b);
+      }
+      exp_share(n);
+      hook(n);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- PV slots: dv block b, query block q -------------------------------------------------------------
+#pragma unroll
+  for (int b = 0; b < kDv16; ++b) {
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+      const int pslot = b * kQ16 + q;
+      mfma_o<false>(o[q][b], va[b % 4], p_prev[q]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v(vb_off, la, b + 4);
+      exp_share(QK_SLOTS + pslot);
+      hook(QK_SLOTS + pslot);
+      if constexpr (HAS_QK) {
+#pragma unroll
+        for (int u = 0; u < MAX_OPS; ++u) {
+          if (MAX_DELAY + u * (PV_SLOTS - MAX_DELAY) / MAX_OPS == pslot) max_op(u);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  finish(ELEMS - 1);
+  group_sum();
+  group_add(ELEMS / 4 - 1);
+}
+
+// Between two steps: pending O rescale, then the decision whether the next block moves a reference.
+template <bool HAS_NEXT>
+__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][kDv16], State (&st)[kQ16], f32x4 (&bias)[kQ16],
+                                         f32x4 (&s_nxt)[2][kQ16], bool& pending, int lane) {
+  bool any_need = false;
+  if constexpr (HAS_NEXT) {
+    const float mxx = fmaxf(fmaxf(st[0].mx_next, st[1].mx_next), fmaxf(st[2].mx_next, st[3].mx_next));
+    any_need = __builtin_amdgcn_ballot_w64(mxx > kDeferLog2) != 0;
+  }
+  if (__builtin_expect(pending || any_need, 0)) {
+    if (pending) {
+      drain_o(o);
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+        for (int b = 0; b < kDv16; ++b) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[q][b][i] *= st[q].alpha;
+        }
+      }
+    }
+    pending = false;
+    if (any_need) {
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) {
+        const float rise = fmaxf(quad_lane_max(st[q].mx_next, lane), 0.f);  // references only move up
+        st[q].alpha = fast_exp2(-rise);
+        st[q].mc += rise;
+        st[q].l *= st[q].alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s_nxt[0][q][i] -= rise;
+          s_nxt[1][q][i] -= rise;
+          bias[q][i] = -st[q].mc;
+        }
+      }
+      // the bias registers are srcC of the next MFMAs
+      asm volatile("s_nop 4" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]));
+      pending = true;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_char* const smem = (lds_char*)smem_raw;
+
+  const uint32_t bid = blockIdx.x;
+  const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
+  const uint32_t per = p.total_wg >> 3, rem = p.total_wg & 7u;
+  const uint32_t item = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + slot_id;
+  const uint32_t head = item / (uint32_t)p.nqt;
+  const uint32_t qt = item - head * (uint32_t)p.nqt;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15;
+  const int g = lane >> 4;
+  const int N = p.N, d = p.d;
+
+  const size_t head_elems = (size_t)N * (size_t)d;
+  const uint32_t head_bytes = (uint32_t)(head_elems * 2);
+  const f16* qh = (const f16*)p.q + (size_t)head * head_elems;
+  const f16* kh = (const f16*)p.k + (size_t)head * head_elems;
+  const f16* vh = (const f16*)p.v + (size_t)head * head_elems;
+  f16* oh = (f16*)p.o + (size_t)head * head_elems;
+  const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qh, 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
+  const srd_t k_srd = make_srd(kh, head_bytes);
+  const srd_t v_srd = make_srd(vh, head_bytes);
+
+  const uint32_t row_bytes = (uint32_t)d * 2u;
+  const uint32_t tile_step = (uint32_t)kBc * row_bytes;
+
+  lds_char* const k_ring = smem;
+  lds_char* const v_ring = smem + kRing * kTileBytes;
+
+  // staging: piece pc = 1 KiB = 4 LDS rows; lane i of it fills chunk i % 16 of row 4 pc + i / 16 with
+  // the source chunk that the swizzle maps there
+  uint32_t dma_off[kPiecesPerWave];
+#pragma unroll
+  for (int i = 0; i < kPiecesPerWave; ++i) {
+    const int ci = (wave * kPiecesPerWave + i) * 64 + lane;
+    const int row = ci / 16;
+    const int src = (ci % 16) ^ swz(row);
+    dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
+  }
+  auto piece = [&](const srd_t srd, lds_char* ring, int slot, int t, int i) __attribute__((always_inline)) {
+    const int pc = wave * kPiecesPerWave + i;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + slot * kTileBytes + pc * 1024));
+    dma_piece(srd, dma_off[i] + (uint32_t)t * tile_step, lds_base);
+  };
+  auto stage = [&](const srd_t srd, lds_char* ring, int slot, int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i) piece(srd, ring, slot, t, i);
+  };
+  auto staged_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  const int nt = (N + kBc - 1) / kBc;
+  stage(k_srd, k_ring, 0, 0);
+  stage(v_srd, v_ring, 0, 0);
+  if (nt > 1) stage(k_srd, k_ring, 1, 1);
+  // Step 0 multiplies P(-1) = 0 with the second block of "V tile -1" (slot 2): make that finite.
+  for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
+    *FLASH_LDS_CAST(u32x4, v_ring + 2 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- Q fragments, pre-multiplied by softmax_scale * log2(e) ------------------------------------------
+  int qrow[kQ16];
+  f16x8 qf[kQ16][kKS];
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+    qrow[q] = (int)qt * kBr + wave * kRowsPerWave + q * 16 + n16;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      const int col = 8 * (ks + 4 * g);
+      const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * 2u : kOob;
+      const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
+      qf[q][ks] = __builtin_bit_cast(f16x8, raw);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
+    }
+  }
+  f32x4 o[kQ16][kDv16];
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) asm volatile("" : "+a"(qf[q][ks]));
+#pragma unroll
+    for (int b = 0; b < kDv16; ++b) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[q][b][i] = 0.f;
+      asm volatile("" : "+a"(o[q][b]));
+    }
+  }
+  const LaneAddr la = make_lane_addr(lane, k_ring, v_ring);
+
+  staged_barrier();
+
+  // ---- prologue: S(0), its row max, the first K fragments of block 1 ----------------------------------
+  f32x4 sA[2][kQ16], sB[2][kQ16];
+  f16x8 pA[kQ16], pB[kQ16];
+  f16x8 ka[4];
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pB[q][j] = (f16)0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) ka[f] = read_k(0u, la, f / kKS, f % kKS);
+#pragma unroll
+  for (int f = 0; f < 2 * kKS; ++f) {
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+      if (f % kKS == 0) {
+        mfma_s_first0(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+      } else {
+        mfma_s<true>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+      }
+    }
+    if (f + 4 < 2 * kKS) {
+      ka[f % 4] = read_k(0u, la, (f + 4) / kKS, (f + 4) % kKS);
+    } else {
+      ka[f % 4] = read_k((uint32_t)kBlkBytes, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
+    }
+  }
+  drain_s(sA);
+  State st[kQ16];
+  f32x4 bias[kQ16];
+  bool pending = false;
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+    mask_tile(sA[0][q], 0, N, lane);
+    mask_tile(sA[1][q], 16, N, lane);
+    float mx = fmaxf(fmaxf(sA[0][q][0], sA[0][q][1]), fmaxf(sA[0][q][2], sA[0][q][3]));
+    mx = fmaxf(mx, fmaxf(fmaxf(sA[1][q][0], sA[1][q][1]), fmaxf(sA[1][q][2], sA[1][q][3])));
+    const float mc = quad_lane_max(mx, lane);  // block 0 always holds key 0, so this is finite
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sA[0][q][i] -= mc;
+      sA[1][q][i] -= mc;
+      bias[q][i] = -mc;
+    }
+    st[q].mc = mc;
+    st[q].l = 0.f;
+    st[q].alpha = 1.f;
+    st[q].mx_next = 0.f;
+  }
+
+  auto tile_iter = [&](auto slot_tag, auto masked_tag, auto last_tag, int t, int slot_rt) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;
+    const int s0 = SLOT >= 0 ? SLOT : slot_rt;
+    const int s1 = s0 == 2 ? 0 : s0 + 1;
+    const int s2 = s1 == 2 ? 0 : s1 + 1;
+    auto no_hook = [](int) __attribute__((always_inline)) {};
+    // staging spread over the slots of the first step: K tile t+2, then V tile t+1
+    auto dma_hook = [&](int n) __attribute__((always_inline)) {
+      constexpr int kSpacing = 64 / (2 * kPiecesPerWave);
+      if (n % kSpacing == 1) {
+        const int i = n / kSpacing;
+        if (i < kPiecesPerWave) {
+          if (t + 2 < nt) piece(k_srd, k_ring, s2, t + 2, i);
+        } else if (i < 2 * kPiecesPerWave) {
+          if (t + 1 < nt) piece(v_srd, v_ring, s1, t + 1, i - kPiecesPerWave);
+        }
+      }
+    };
+    const uint32_t k_cur = (uint32_t)(s0 * kTileBytes);
+    const uint32_t k_nxt = (uint32_t)(s1 * kTileBytes);
+    const uint32_t v_cur = (uint32_t)(s0 * kTileBytes);
+    const uint32_t v_prv = (uint32_t)(s2 * kTileBytes);
+    pipeline_step<true, !LAST, MASKED>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
+                                       pB, pA, st, t * kBc + 32, N, lane);
+    step_end<true>(o, st, bias, sB, pending, lane);
+    pipeline_step<!LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
+                                        (t + 1) * kBc, N, lane);
+    step_end<!LAST>(o, st, bias, sA, pending, lane);
+    staged_barrier();
+  };
+  using std::integral_constant;
+  constexpr std::true_type yes{};
+  constexpr std::false_type no{};
+  int t = 0;
+  for (; t + 5 <= nt; t += 3) {
+    tile_iter(integral_constant<int, 0>{}, no, no, t, 0);
+    tile_iter(integral_constant<int, 1>{}, no, no, t + 1, 1);
+    tile_iter(integral_constant<int, 2>{}, no, no, t + 2, 2);
+  }
+  for (; t + 1 < nt; ++t) tile_iter(integral_constant<int, -1>{}, yes, no, t, t % 3);
+  tile_iter(integral_constant<int, -1>{}, yes, yes, t, t % 3);
+  // PV of the last block
+  {
+    drain_o(o);
+    const uint32_t vb = (uint32_t)(((nt - 1) % 3) * kTileBytes + kBlkBytes);
+#pragma unroll
+    for (int b = 0; b < kDv16; ++b) {
+      const f16x8 vf = read_v(vb, la, b);
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
+    }
+    drain_o(o);
+  }
+
+  // ---- epilogue: O = O^T / l.  Tile b of query block q holds dv = 16b + 4g + 0..3 of the lane's query.
+  // Two neighbouring tiles are exchanged between 16-lane rows (v_permlane16_swap) so that a lane owns 8
+  // consecutive columns of one of them and writes one 128-bit store.
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+    const float inv = 1.0f / quad_lane_sum(st[q].l, lane);
+#pragma unroll
+    for (int b = 0; b < kDv16; b += 2) {
+      f16x4 x, y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = (f16)(o[q][b][j] * inv);
+        y[j] = (f16)(o[q][b + 1][j] * inv);
+      }
+      const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+      u32x4 out;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        // odd rows of the first operand trade places with even rows of the second
+        auto r = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
+        out[w] = r[0];      // g even: own tile b, cols 4g..      g odd: tile b+1 of row g-1
+        out[2 + w] = r[1];  // g even: tile b of row g+1          g odd: own tile b+1
+      }
+      const int dv = 16 * (b + (g & 1)) + 8 * (g >> 1);
+      const uint32_t off = (dv < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+}  // namespace m16
+}  // namespace flash_hip

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "attn_fwd_mfma.hpp"
+#include "attn_fwd_mfma16.hpp"
 
 namespace {
 
@@ -72,12 +73,25 @@ int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool 
   return FLASH_HIP_OK;
 }
 
+template <typename Kernel>
+int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16]);
+
 template <int D, typename T, bool FAST>
 int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
-  auto kern = attn_fwd_kernel<D, T, FAST>;
+  static thread_local bool attr_done[16] = {};
+  return launch_kernel(attn_fwd_kernel<D, T, FAST>, prm, lds, stream, attr_done);
+}
+
+// head-dim tile 128, fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel
+int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
+  static thread_local bool attr_done[16] = {};
+  return launch_kernel(m16::attn_fwd_kernel_m16, prm, lds, stream, attr_done);
+}
+
+template <typename Kernel>
+int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16]) {
   // Above the 64 KiB default a kernel must opt in to its dynamic LDS size (the reference does the
   // same above 48 KiB, launch.cu:134-148).
-  static thread_local bool attr_done[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   if (dev < 16 && !attr_done[dev]) {
@@ -112,7 +126,12 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   hipStream_t stream = (hipStream_t)hip_stream;
   if constexpr (sizeof(T) == 2) {
     if (plan.fast) {
+#if defined(FLASH_D128_MFMA32)
       return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
+#else
+      static_assert(m16::kLdsBytes == Geom<128>::kLdsBytes, "both 128-wide kernels use the same LDS rings");
+      return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch_m16(prm, plan.lds, stream);
+#endif
     }
   }
   return plan.tile_d == 64 ? launch<64, T, false>(prm, plan.lds, stream) : launch<128, T, false>(prm, plan.lds, stream);
