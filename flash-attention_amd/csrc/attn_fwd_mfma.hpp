@@ -74,7 +74,28 @@ struct FwdParams {
   int nqt;            // query tiles per head = ceil(N / kBr)
   uint32_t total_wg;  // B * H * nqt
   float scale_log2e;  // softmax_scale * log2(e)
+#if defined(FLASH_PHASE_STAMPS)
+  unsigned long long* stamps;  // diagnostic builds only: 8 values per wave (see tools/README.md)
+#endif
 };
+
+// Diagnostic builds (-DFLASH_PHASE_STAMPS) record the shader clock at a few points of a wave's life;
+// the values go to a buffer of their own and nothing is computed from them.
+#if defined(FLASH_PHASE_STAMPS)
+#define FLASH_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define FLASH_STAMP_STORE(prm, wave_id, lane_id, t0, t1, t2, t3)                                   \
+  do {                                                                                              \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+    const unsigned long long t4_ = __builtin_amdgcn_s_memtime();                                   \
+    if ((prm).stamps && (lane_id) == 0) {                                                           \
+      unsigned long long* d_ = (prm).stamps + ((size_t)blockIdx.x * kWaves + (wave_id)) * 8;       \
+      d_[0] = t0; d_[1] = t1; d_[2] = t2; d_[3] = t3; d_[4] = t4_;                                  \
+    }                                                                                               \
+  } while (0)
+#else
+#define FLASH_STAMP(var)
+#define FLASH_STAMP_STORE(prm, wave_id, lane_id, t0, t1, t2, t3)
+#endif
 
 template <int D>
 struct Geom {

@@ -244,8 +244,9 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     } else if (k == 2) {
       mx[q] = fmaxf(fmaxf(mx[q], t1[1]), t1[2]);
     } else {
-      mx[q] = fmaxf(mx[q], t1[3]);
-      st[q].mx_next = mx[q];
+      st[q].mx_next = fmaxf(mx[q], t1[3]);
+      asm volatile("" : "+v"(st[q].mx_next));
+      return;
     }
     asm volatile("" : "+v"(mx[q]));
   };
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_char* const smem = (lds_char*)smem_raw;
+  FLASH_STAMP(stamp_start);
 
   const uint32_t bid = blockIdx.x;
   const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
@@ -411,15 +413,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   };
 
   const int nt = (N + kBc - 1) / kBc;
-  stage(k_srd, k_ring, 0, 0);
-  stage(v_srd, v_ring, 0, 0);
-  if (nt > 1) stage(k_srd, k_ring, 1, 1);
-  // Step 0 multiplies P(-1) = 0 with the second block of "V tile -1" (slot 2): make that finite.
-  for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
-    *FLASH_LDS_CAST(u32x4, v_ring + 2 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
-  }
 
   // ---- Q fragments, pre-multiplied by softmax_scale * log2(e) ------------------------------------------
+  // The loads are issued before the K/V staging traffic: loads return in order, so the conversion of
+  // Q overlaps the tiles that are still in flight.
   int qrow[kQ16];
   f16x8 qf[kQ16][kKS];
 #pragma unroll
@@ -431,6 +428,19 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * 2u : kOob;
       const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
       qf[q][ks] = __builtin_bit_cast(f16x8, raw);
+    }
+  }
+  stage(k_srd, k_ring, 0, 0);
+  stage(v_srd, v_ring, 0, 0);
+  if (nt > 1) stage(k_srd, k_ring, 1, 1);
+  // Step 0 multiplies P(-1) = 0 with the second block of "V tile -1" (slot 2): make that finite.
+  for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
+    *FLASH_LDS_CAST(u32x4, v_ring + 2 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
     }
@@ -501,6 +511,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     st[q].mx_next = 0.f;
   }
 
+  FLASH_STAMP(stamp_loop);
   auto tile_iter = [&](auto slot_tag, auto masked_tag, auto last_tag, int t, int slot_rt) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     constexpr bool MASKED = decltype(masked_tag)::value;
@@ -544,6 +555,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   }
   for (; t + 1 < nt; ++t) tile_iter(integral_constant<int, -1>{}, yes, no, t, t % 3);
   tile_iter(integral_constant<int, -1>{}, yes, yes, t, t % 3);
+  FLASH_STAMP(stamp_tail);
   // PV of the last block
   {
     drain_o(o);
@@ -585,6 +597,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
     }
   }
+  FLASH_STAMP(stamp_end);
+  FLASH_STAMP_STORE(p, wave, lane, stamp_start, stamp_loop, stamp_tail, stamp_end);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

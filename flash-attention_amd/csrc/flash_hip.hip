@@ -13,6 +13,10 @@
 
 #include "attn_fwd_mfma.hpp"
 #include "attn_fwd_mfma16.hpp"
+#if defined(FLASH_PHASE_STAMPS)
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace {
 
@@ -100,7 +104,37 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
       return fail(FLASH_HIP_ERR_LDS, "Failed to set dynamic shared memory size %u: %s", lds, hipGetErrorString(e));
     attr_done[dev] = true;
   }
+#if defined(FLASH_PHASE_STAMPS)
+  // diagnostic build: collect and print the per-wave phase stamps of this launch (synchronises)
+  {
+    static unsigned long long* buf = nullptr;
+    static size_t cap = 0;
+    const size_t n = (size_t)prm.total_wg * kWaves * 8;
+    if (n > cap) {
+      (void)hipMalloc(&buf, n * 8);
+      cap = n;
+    }
+    (void)hipMemsetAsync(buf, 0, n * 8, stream);
+    FwdParams prm2 = prm;
+    prm2.stamps = buf;
+    hipLaunchKernelGGL(kern, dim3(prm.total_wg), dim3(kThreads), lds, stream, prm2);
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned long long> h(n);
+    (void)hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost);
+    double ph[4] = {0, 0, 0, 0};
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; i += 8) {
+      if (h[i + 4] == 0) continue;  // kernel without stamps
+      for (int k = 0; k < 4; ++k) ph[k] += (double)(h[i + k + 1] - h[i + k]);
+      ++cnt;
+    }
+    if (cnt)
+      fprintf(stderr, "[stamps] cycles per wave: prologue %.0f  loop %.0f  tail+epilogue issue %.0f  store drain %.0f  (%zu waves)\n",
+              ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, cnt);
+  }
+#else
   hipLaunchKernelGGL(kern, dim3(prm.total_wg), dim3(kThreads), lds, stream, prm);
+#endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
   return FLASH_HIP_OK;

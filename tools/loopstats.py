@@ -14,7 +14,7 @@ for i,l in enumerate(raw):
                 break
 lines=[l.strip() for l in raw[start:end+1] if l.strip() and not l.strip().startswith(';')]
 ops=collections.Counter(l.split()[0] for l in lines if not l.startswith('.L'))
-print('loop lines',len(lines),'mfma',ops['v_mfma_f32_32x32x16_f16'])
+print('loop lines',len(lines),'mfma',ops['v_mfma_f32_16x16x32_f16'])
 print(ops.most_common(50))
 gaps=[];g=[]
 for l in lines:
