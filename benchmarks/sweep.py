@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Sequence-length sweep of the attention forward on one MI355X.
+
+Counterpart of the reference's scalability study (reference benchmarks/bench.py:89-111, the data
+behind its img/scalability.png): B=4, H=96, d=128 (bench.py:28-31), N = 512 ... 16384, one row per
+implementation, times in milliseconds in a dict of the same shape
+    {"Sequence Length": [...], "<kernel name>": [ms, ...], ...}
+so the reference's plot can be regenerated from it.  Differences, on purpose: inputs are fp16 (the
+native kernel's storage type), every kernel is warmed up and the median of several HIP-event timings
+is reported (the reference profiles one cold call, bench.py:58-66), and TFLOP/s = 4*B*H*N^2*d / t is
+printed next to the times.
+
+Rows
+  manual_attn        softmax(q @ k^T / sqrt(d)) @ v with torch ops in fp16 (0 where it runs out of memory)
+  mma_qreg_vld       torch.ops.pyflash.mma_qreg_vld   -> native kernel
+  mma_qreg_async     torch.ops.pyflash.mma_qreg_async -> native kernel
+  torch_flash_v2     torch.nn.functional.scaled_dot_product_attention in fp16 (whatever backend
+                     PyTorch-ROCm selects)
+
+  python benchmarks/sweep.py [--out profiles/sweep.json] [--max-n 16384] [--reps 10]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import math
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--max-n", type=int, default=16384)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--heads", type=int, default=96)
+    ap.add_argument("--head-dim", type=int, default=128)
+    args = ap.parse_args()
+
+    import torch
+    import torch.nn.functional as F
+
+    fa = importlib.import_module("flash-attention_amd")
+    fa.load_pyflash()
+    pyflash = torch.ops.pyflash
+    if not torch.cuda.is_available():
+        raise SystemExit("sweep.py needs a HIP device")
+    dev = torch.device("cuda", 0)
+    B, H, d = args.batch, args.heads, args.head_dim
+
+    def manual_attn(q, k, v):
+        att = torch.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(d)), dim=-1)
+        return att @ v
+
+    rows = [
+        ("manual_attn", manual_attn),
+        ("mma_qreg_vld", pyflash.mma_qreg_vld),
+        ("mma_qreg_async", pyflash.mma_qreg_async),
+        ("torch_flash_v2", F.scaled_dot_product_attention),
+    ]
+
+    def time_ms(fn, q, k, v):
+        for _ in range(3):
+            fn(q, k, v)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(args.reps):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(q, k, v)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return statistics.median(ts)
+
+    seqs = [n for n in (512, 1024, 2048, 4096, 8192, 16384) if n <= args.max_n]
+    data = {"Sequence Length": seqs}
+    tflops = {}
+    gen = torch.Generator(device=dev).manual_seed(0)
+    for N in seqs:
+        q, k, v = (torch.randn(B, H, N, d, device=dev, generator=gen).half() for _ in range(3))
+        flops = 4.0 * B * H * N * N * d
+        print(f"\nseq_len {N}", flush=True)
+        ref = None
+        for name, fn in rows:
+            try:
+                ms = time_ms(fn, q, k, v)
+                if name == "torch_flash_v2":
+                    ref = fn(q, k, v)
+            except torch.OutOfMemoryError as e:   # the N x N score matrix of manual_attn at long N
+                ms = 0.0
+                print("  out of memory:", str(e).split("\n")[0])
+                torch.cuda.empty_cache()
+            data.setdefault(name, []).append(round(ms, 4))
+            tflops.setdefault(name, []).append(round(flops / (ms * 1e-3) / 1e12, 1) if ms else 0.0)
+            print(f"  {name}: {ms:.3f} ms  {tflops[name][-1]} TFLOP/s", flush=True)
+        if ref is not None:
+            err = float((pyflash.mma_qreg_async(q, k, v).float() - ref.float()).abs().max())
+            print(f"  max |native - torch SDPA| = {err:.2e}")
+        del q, k, v
+        torch.cuda.empty_cache()
+
+    print()
+    print(data)
+    result = {"shape": {"B": B, "H": H, "d": d, "dtype": "fp16"}, "ms": data, "tflops": tflops,
+              "method": f"median of {args.reps} HIP-event timings after 3 warm-up calls, one MI355X",
+              "torch": torch.__version__}
+    if args.out:
+        with open(args.out, "w") as f:
+            json.dump(result, f, indent=1)
+        print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()

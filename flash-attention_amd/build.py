@@ -1,5 +1,4 @@
-"""In-tree build of every native artefact (no cmake needed; a CMakeLists.txt with the same
-targets sits next to this file for users who prefer the reference's workflow).
+"""In-tree build of every native artefact (plain compiler invocations, no cmake needed).
 
   flash-attention_amd/lib/libflash_hip.so   HIP kernels + C ABI            (hipcc --offload-arch=gfx950)
   build/libflash.a                          flash::forward on libtorch     (g++)
@@ -7,6 +6,8 @@ targets sits next to this file for users who prefer the reference's workflow).
   build/runner                              correctness tests / benchmark  (g++)
   tests/native/selftest                     torch-free parity harness      (hipcc host + oracle)
   oracle/liboracle.so                       CPU oracle (test infrastructure only)
+  build/flash_hip.s                         device assembly of the kernels, on request (`asm`), for
+                                            tests/test_kernel_asm.py and tools/loopstats.py
 
 Steps are skipped when the output is newer than all of its inputs.
 """
@@ -50,8 +51,22 @@ def build_hip_library(force=False):
     srcs = glob.glob(os.path.join(HERE, "csrc", "*")) + [os.path.join(ROOT, "include", "flash_hip.h")]
     if force or _stale(out, srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        _run([_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fno-honor-nans", "-fPIC", "-shared",
+        _run([_hipcc(), f"--offload-arch={ARCH}"] + HIP_FLAGS + ["-fPIC", "-shared",
               os.path.join(HERE, "csrc", "flash_hip.hip"), "-o", out])
+    return out
+
+
+HIP_FLAGS = ["-O3", "-std=c++17", "-fno-honor-nans"]
+
+
+def build_device_asm(force=False):
+    """gfx950 assembly of every kernel in the library (same flags as the library itself)."""
+    out = os.path.join(BUILD, "flash_hip.s")
+    srcs = glob.glob(os.path.join(HERE, "csrc", "*")) + [os.path.join(ROOT, "include", "flash_hip.h")]
+    if force or _stale(out, srcs):
+        os.makedirs(BUILD, exist_ok=True)
+        _run([_hipcc(), f"--offload-arch={ARCH}"] + HIP_FLAGS + ["--cuda-device-only", "-S",
+             os.path.join(HERE, "csrc", "flash_hip.hip"), "-o", out])
     return out
 
 
@@ -148,4 +163,7 @@ def build_all(force=False, with_torch=True):
 
 
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv, with_torch="--no-torch" not in sys.argv)
+    if "asm" in sys.argv:
+        build_device_asm(force="--force" in sys.argv)
+    else:
+        build_all(force="--force" in sys.argv, with_torch="--no-torch" not in sys.argv)

@@ -1,0 +1,102 @@
+"""CPU only: properties of the generated gfx950 code that the kernels rely on but the compiler does
+not promise.  The MFMAs are issued from inline asm, so the compiler pads no hazards for them and is
+free to park their operands in the other register file; these checks read the device assembly.
+
+  * no kernel spills to scratch;
+  * in the tuned kernels' main loops no value moves between the VGPR and AGPR files (a
+    v_accvgpr_write placed right in front of an unpadded MFMA would be read too early);
+  * the main loops hold exactly the expected number of MFMAs per unrolled tile triple;
+  * dynamic LDS stays within the 160 KiB of a CU.
+"""
+import importlib.util
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def asm_text():
+    spec = importlib.util.spec_from_file_location("fa_build", os.path.join(ROOT, "flash-attention_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = mod.build_device_asm()
+    with open(path) as f:
+        return f.read()
+
+
+def kernels(asm_text):
+    """name -> list of instruction lines (labels kept, comments and directives dropped)."""
+    out = {}
+    for m in re.finditer(r"^(_ZN9flash_hip\S*attn_fwd_kernel[^:\s]*):[^\n]*\n(.*?)^\s*s_endpgm", asm_text, re.S | re.M):
+        body = [l.strip() for l in m.group(2).split("\n")]
+        out[m.group(1)] = [l for l in body if l and not l.startswith(";") and not l.startswith(".") or l.startswith(".LBB")]
+    return out
+
+
+def main_loop(lines):
+    """Instruction lines of the innermost loop that holds at least 90 MFMAs (the unrolled tile triple)."""
+    for i, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if not m:
+            continue
+        lab = m.group(1)
+        for j in range(i + 1, len(lines)):
+            if re.search(r"s_cbranch_\w+\s+" + re.escape(lab) + r"\b", lines[j]):
+                body = lines[i:j + 1]
+                if sum("v_mfma" in x for x in body) >= 90:
+                    return body
+                break
+    return None
+
+
+def test_no_kernel_spills(asm_text):
+    names = re.findall(r"\.name:\s+(_ZN9flash_hip\S*attn_fwd_kernel\S*)", asm_text)
+    assert len(names) >= 6, names
+    for field in ("vgpr_spill_count", "sgpr_spill_count"):
+        vals = re.findall(r"\." + field + r":\s+(\d+)", asm_text)
+        assert vals and all(v == "0" for v in vals), (field, vals)
+    assert not re.search(r"\.private_segment_fixed_size:\s+[1-9]", asm_text), "a kernel uses scratch memory"
+    for lds in re.findall(r"\.group_segment_fixed_size:\s+(\d+)", asm_text):
+        assert int(lds) <= 160 * 1024
+
+
+TUNED = {
+    # kernel-name fragment -> MFMAs per unrolled triple of tile iterations (6 steps)
+    "attn_fwd_kernel_m16": 6 * 64,               # d=128 tile on 16x16x32: 32 QK + 32 PV per step
+    "attn_fwd_kernelILi64EDF16_Lb1": 6 * 18,     # d=64 tile on 32x32x16: 2 bias + 8 QK + 8 PV per step
+}
+
+
+@pytest.mark.parametrize("frag", sorted(TUNED))
+def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
+    ks = {n: l for n, l in kernels(asm_text).items() if frag in n}
+    assert len(ks) == 1, list(ks)
+    lines = next(iter(ks.values()))
+    loop = main_loop(lines)
+    assert loop is not None, "main loop not found"
+    n_mfma = sum("v_mfma" in l for l in loop)
+    assert n_mfma == TUNED[frag], n_mfma
+    moves = [l for l in loop if l.startswith("v_accvgpr_")]
+    assert not moves, f"{len(moves)} VGPR<->AGPR moves in the main loop, e.g. {moves[:3]}"
+    assert not any("scratch_" in l or "buffer_store" in l for l in loop)
+    # one barrier per tile iteration
+    assert sum(l.startswith("s_barrier") for l in loop) == 3
+
+
+def test_every_unpadded_mfma_is_clear_of_accvgpr_writes(asm_text):
+    """Anywhere in the tuned kernels: an MFMA issued without its own s_nop prefix must not follow a
+    v_accvgpr_write within two instructions."""
+    for name, lines in kernels(asm_text).items():
+        if not any(f in name for f in TUNED):
+            continue
+        ins = [l for l in lines if not l.startswith(".LBB")]
+        for i, l in enumerate(ins):
+            if "v_mfma" not in l:
+                continue
+            prev = ins[max(0, i - 2):i]
+            if any(p.startswith("s_nop") for p in prev[-1:]):
+                continue
+            assert not any(p.startswith("v_accvgpr_write") for p in prev), (name, prev, l)
