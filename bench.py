@@ -181,7 +181,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
                 "traffic": measured_traffic(args.workload),
-                "kernel": "flash_hip::attn_fwd_kernel",
+                "kernel": "flash_hip::m16::attn_fwd_kernel_m16" if d == 128 else "flash_hip::attn_fwd_kernel<64, f16, true>",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops,
             },
