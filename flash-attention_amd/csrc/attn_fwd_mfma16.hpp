@@ -1,5 +1,5 @@
-// FlashAttention-2 forward for gfx950, head-dim tile 128, fp16 rows of a multiple of 8 elements,
-// built on v_mfma_f32_16x16x32_f16.
+// FlashAttention-2 forward for gfx950, head-dim tiles 64 and 128, fp16 rows of a multiple of 8
+// elements, built on v_mfma_f32_16x16x32_f16.
 //
 // Same structure as attn_fwd_mfma.hpp (4 waves, one per SIMD, 64 query rows each; transposed
 // products S^T = K Q^T and O^T = V^T P^T so that a lane owns one query column; K/V in 3-slot LDS
@@ -14,8 +14,9 @@
 //
 // Fragment maps (lane l: n = l & 15, g = l >> 4):
 //   A (16 x 32): row n, k = 8g + j.   B (32 x 16): k = 8g + j, column n.   C/D: column n, rows 4g + i.
-//   S^T tile (16 keys x 16 queries), k-step ks: A = K[key n][chunk ks + 4g] (one ds_read_b128; the
-//     chunk permutation makes the read conflict-free), B = Q[query n][chunk ks + 4g] from AGPRs.
+//   S^T tile (16 keys x 16 queries), k-step ks of KS = D/32: A = K[key n][16-byte chunk ks + KS*g]
+//     (one ds_read_b128; the chunk permutation makes the read conflict-free), B = Q[query n][same
+//     chunk] from AGPRs.
 //     The lane ends up with keys 4g + i of key block kb for its query.
 //   P^T fragment of a 32-key block: element j < 4 is key 4g + j of key block 0, j >= 4 key 4g + j - 4
 //     of key block 1: exactly the two S^T tiles of the block converted to fp16, no lane movement.
@@ -29,25 +30,42 @@ namespace m16 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kD = 128;
-constexpr int kQ16 = 4;                       // 16-row query blocks per wave
-constexpr int kDv16 = kD / 16;                // 16-row blocks of O^T
-constexpr int kKS = kD / 32;                  // k-steps of a score tile
-constexpr int kRowBytes = kD * 2;
-constexpr int kTileBytes = kBc * kRowBytes;   // 16 KiB
-constexpr int kRing = 3;
-constexpr int kLdsBytes = 2 * kRing * kTileBytes;
-constexpr int kPiecesPerWave = kTileBytes / 1024 / 4;
-constexpr int kBlkBytes = 32 * kRowBytes;     // one 32-key block
+constexpr int kQ16 = 4;   // 16-row query blocks per wave
+constexpr int kRing = 3;  // tiles per LDS ring
 static_assert(kWaves == 4 && kRowsPerWave == 64, "written for one wave per SIMD with 64 query rows");
 
-// 16-byte-chunk XOR swizzle of a 256-byte LDS row, f(row) = 2*(row & 7) | bit 3 of row:
-//  - ds_read_b128 of chunk ks + 4g of rows 0..15 (K operand): every 16-lane service group of the
-//    instruction touches 16 different 16-byte slots;
+template <int D>
+struct Cfg {
+  static_assert(D == 64 || D == 128, "compiled head-dim tiles are 64 and 128");
+  static constexpr int kDv16 = D / 16;                 // 16-row blocks of O^T
+  static constexpr int kKS = D / 32;                   // k-steps of a score tile
+  static constexpr int kChunks = D / 8;                // 16-byte chunks per row
+  static constexpr int kRowBytes = D * 2;
+  static constexpr int kTileBytes = kBc * kRowBytes;
+  static constexpr int kLdsBytes = 2 * kRing * kTileBytes;
+  static constexpr int kPiecesPerWave = kTileBytes / 1024 / kWaves;
+  static constexpr int kBlkBytes = 32 * kRowBytes;     // one 32-key block
+};
+
+// 16-byte-chunk XOR swizzle f(row) of an LDS row, chosen per row length so that
+//  - ds_read_b128 of chunk ks + KS*g of rows 0..15 (K operand): every 16-lane service group of the
+//    instruction touches 16 different 16-byte slots of the 256-byte bank line;
 //  - ds_read_b64_tr_b16 of 32 bytes of each of rows 4g..4g+3 (V operand): the 8 rows of a half-wave
 //    land on 8 different 32-byte slot pairs.
-__device__ __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ swz(row)) << 4); }
+// 256-byte rows: f = 2*(row & 7) | bit 3 of row.  128-byte rows (two per bank line, the row parity
+// picks the half): f = 2*((row >> 1) & 3) | bit 3 of row.
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if constexpr (D == 128) {
+    return ((row & 7) << 1) | ((row >> 3) & 1);
+  } else {
+    return (((row >> 1) & 3) << 1) | ((row >> 3) & 1);
+  }
+}
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * Cfg<D>::kRowBytes + ((chunk ^ swz<D>(row)) << 4);
+}
 
 // S^T tile: first k-step takes srcC from `c0` (the bias registers or 0), later ones accumulate.
 __device__ __forceinline__ void mfma_s_first(f32x4& acc, const f16x8& a, const f16x8& b, const f32x4& c0) {
@@ -76,12 +94,14 @@ __device__ __forceinline__ void mfma_o(f32x4& acc, const f16x8& a, const f16x8& 
 // Wait states for the last MFMAs, with the accumulators as operands so that their readers stay
 // behind the wait.  The statements are volatile, hence ordered among themselves: the first one
 // carries the wait, the others only tie the remaining registers to that order.
-__device__ __forceinline__ void drain_o(f32x4 (&o)[kQ16][kDv16]) {
+template <int NB>
+__device__ __forceinline__ void drain_o(f32x4 (&o)[kQ16][NB]) {
+  static_assert(NB == 4 || NB == 8, "operand lists are written out for these sizes");
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {
-    asm volatile("" : "+a"(o[q][0]), "+a"(o[q][1]), "+a"(o[q][2]), "+a"(o[q][3]), "+a"(o[q][4]), "+a"(o[q][5]),
-                 "+a"(o[q][6]), "+a"(o[q][7]));
+    asm volatile("" : "+a"(o[q][0]), "+a"(o[q][1]), "+a"(o[q][2]), "+a"(o[q][3]));
+    if constexpr (NB == 8) asm volatile("" : "+a"(o[q][4]), "+a"(o[q][5]), "+a"(o[q][6]), "+a"(o[q][7]));
   }
 }
 __device__ __forceinline__ void drain_s(f32x4 (&s)[2][kQ16]) {
@@ -104,25 +124,28 @@ __device__ __forceinline__ float quad_lane_sum(float x, int lane) {
   return x + y;
 }
 
+template <int D>
 struct LaneAddr {
-  uint32_t k[kKS];    // K[row n][chunk ks + 4g] of slot 0 / row block 0
-  uint32_t v[kDv16];  // V rows 4g + (i16 >> 2), 8-byte piece (i16 & 3) of dv block b
+  uint32_t k[Cfg<D>::kKS];    // K[row n][chunk ks + KS*g] of slot 0 / row block 0
+  uint32_t v[Cfg<D>::kDv16];  // V rows 4g + (i16 >> 2), 8-byte piece (i16 & 3) of dv block b
 };
 
-__device__ __forceinline__ LaneAddr make_lane_addr(int lane, lds_char* k_ring, lds_char* v_ring) {
-  LaneAddr la;
+template <int D>
+__device__ __forceinline__ LaneAddr<D> make_lane_addr(int lane, lds_char* k_ring, lds_char* v_ring) {
+  constexpr int kKS = Cfg<D>::kKS, kDv16 = Cfg<D>::kDv16;
+  LaneAddr<D> la;
   const int n = lane & 15, g = lane >> 4;
   const int tq = n >> 2, tp = n & 3;
   const uint32_t kbase = (uint32_t)(uintptr_t)k_ring, vbase = (uint32_t)(uintptr_t)v_ring;
 #pragma unroll
   for (int ks = 0; ks < kKS; ++ks) {
-    uint32_t a = kbase + (uint32_t)lds_off(n, ks + 4 * g);
+    uint32_t a = kbase + (uint32_t)lds_off<D>(n, ks + kKS * g);
     asm volatile("" : "+v"(a));
     la.k[ks] = a;
   }
 #pragma unroll
   for (int b = 0; b < kDv16; ++b) {
-    uint32_t a = vbase + (uint32_t)(lds_off(4 * g + tq, 2 * b + (tp >> 1)) + 8 * (tp & 1));
+    uint32_t a = vbase + (uint32_t)(lds_off<D>(4 * g + tq, 2 * b + (tp >> 1)) + 8 * (tp & 1));
     asm volatile("" : "+v"(a));
     la.v[b] = a;
   }
@@ -130,15 +153,17 @@ __device__ __forceinline__ LaneAddr make_lane_addr(int lane, lds_char* k_ring, l
 }
 
 // K fragment: 16-row block rb (0..3 inside a 64-row tile) of the tile that starts `koff` bytes into the ring.
-__device__ __forceinline__ f16x8 read_k(uint32_t koff, const LaneAddr& la, int rb, int ks) {
-  return *(FLASH_LDS_CAST(f16x8, (uintptr_t)(la.k[ks] + koff + (uint32_t)(rb * 16 * kRowBytes))));
+template <int D>
+__device__ __forceinline__ f16x8 read_k(uint32_t koff, const LaneAddr<D>& la, int rb, int ks) {
+  return *(FLASH_LDS_CAST(f16x8, (uintptr_t)(la.k[ks] + koff + (uint32_t)(rb * 16 * Cfg<D>::kRowBytes))));
 }
 // V^T fragment of dv block b for the 32-key block that starts `voff` bytes into the ring.
-__device__ __forceinline__ f16x8 read_v(uint32_t voff, const LaneAddr& la, int b) {
+template <int D>
+__device__ __forceinline__ f16x8 read_v(uint32_t voff, const LaneAddr<D>& la, int b) {
   f16x8 a;
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) {
-    const uint32_t addr = la.v[b] + voff + (uint32_t)(jj * 16 * kRowBytes);
+    const uint32_t addr = la.v[b] + voff + (uint32_t)(jj * 16 * Cfg<D>::kRowBytes);
     const fp16x4_b t = __builtin_amdgcn_ds_read_tr16_b64_v4f16(FLASH_LDS_CAST(fp16x4_b, (uintptr_t)addr));
     const f16x4 tv = __builtin_bit_cast(f16x4, t);
     a[4 * jj + 0] = tv[0];
@@ -168,15 +193,16 @@ __device__ __forceinline__ void mask_tile(f32x4& s, int kv_tile0, int N, int lan
 // One pipeline step: QK(j+1) (32 MFMAs), PV(j-1) (32 MFMAs), exp(j), in-lane max(j+1).
 //   s_cur/s_nxt[kb][q]: S^T tiles of key block kb (16 keys) and query block q (16 queries)
 //   p_prev/p_cur[q]:    P^T fragments (32 keys) of query block q
-template <bool HAS_QK, bool HAS_PRELOAD, bool MASKED, typename Hook>
+template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, typename Hook>
 __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off, uint32_t vb_off, uint32_t kb_next_off,
-                                              const LaneAddr& la, const f32x4 (&bias)[kQ16],
-                                              const f16x8 (&qf)[kQ16][kKS], f16x8 (&ka)[4],
-                                              f32x4 (&o)[kQ16][kDv16], const f32x4 (&s_cur)[2][kQ16],
+                                              const LaneAddr<D>& la, const f32x4 (&bias)[kQ16],
+                                              const f16x8 (&qf)[kQ16][Cfg<D>::kKS], f16x8 (&ka)[4],
+                                              f32x4 (&o)[kQ16][Cfg<D>::kDv16], const f32x4 (&s_cur)[2][kQ16],
                                               f32x4 (&s_nxt)[2][kQ16], const f16x8 (&p_prev)[kQ16],
                                               f16x8 (&p_cur)[kQ16], State (&st)[kQ16], int kv_next0, int N, int lane) {
-  constexpr int QK_SLOTS = 2 * kKS * kQ16;  // 32
-  constexpr int PV_SLOTS = kDv16 * kQ16;    // 32
+  constexpr int kKS = Cfg<D>::kKS, kDv16 = Cfg<D>::kDv16;
+  constexpr int QK_SLOTS = 2 * kKS * kQ16;  // 32 (D = 128), 16 (D = 64)
+  constexpr int PV_SLOTS = kDv16 * kQ16;    // 32, 16
   constexpr int SLOTS = QK_SLOTS + PV_SLOTS;
   constexpr int ELEMS = 8 * kQ16;           // scores per lane and step
   constexpr int MAX_OPS = 4 * kQ16;
@@ -267,16 +293,16 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
         __builtin_amdgcn_sched_barrier(0);
         if (q == kQ16 - 1) {
           if (f + 4 < 2 * kKS) {
-            ka[f % 4] = read_k(kb_off, la, (f + 4) / kKS, (f + 4) % kKS);
+            ka[f % 4] = read_k<D>(kb_off, la, (f + 4) / kKS, (f + 4) % kKS);
           } else if constexpr (HAS_PRELOAD) {
-            ka[f % 4] = read_k(kb_next_off, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
+            ka[f % 4] = read_k<D>(kb_next_off, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
           }
         }
       }
       // the first four V^T fragments, shortly before the PV slots begin
       if (n >= QK_SLOTS - 10 && n < QK_SLOTS - 2 && ((n - (QK_SLOTS - 10)) & 1) == 0) {
         const int b = (n - (QK_SLOTS - 10)) / 2;
-        va[b] = read_v(vb_off, la, b);
+        va[b] = read_v<D>(vb_off, la, b);
       }
       exp_share(n);
       hook(n);
@@ -291,7 +317,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
       const int pslot = b * kQ16 + q;
       mfma_o<false>(o[q][b], va[b % 4], p_prev[q]);
       __builtin_amdgcn_sched_barrier(0);
-      if (q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v(vb_off, la, b + 4);
+      if (q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
       exp_share(QK_SLOTS + pslot);
       hook(QK_SLOTS + pslot);
       if constexpr (HAS_QK) {
@@ -309,8 +335,8 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
 }
 
 // Between two steps: pending O rescale, then the decision whether the next block moves a reference.
-template <bool HAS_NEXT>
-__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][kDv16], State (&st)[kQ16], f32x4 (&bias)[kQ16],
+template <int NB, bool HAS_NEXT>
+__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], f32x4 (&bias)[kQ16],
                                          f32x4 (&s_nxt)[2][kQ16], bool& pending, int lane) {
   bool any_need = false;
   if constexpr (HAS_NEXT) {
@@ -323,7 +349,7 @@ __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][kDv16], State (&st)[kQ
 #pragma unroll
       for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
-        for (int b = 0; b < kDv16; ++b) {
+        for (int b = 0; b < NB; ++b) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) o[q][b][i] *= st[q].alpha;
         }
@@ -351,8 +377,12 @@ __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][kDv16], State (&st)[kQ
   }
 }
 
+template <int D>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  using C = Cfg<D>;
+  constexpr int kKS = C::kKS, kDv16 = C::kDv16, kTileBytes = C::kTileBytes, kBlkBytes = C::kBlkBytes;
+  constexpr int kPiecesPerWave = C::kPiecesPerWave;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_char* const smem = (lds_char*)smem_raw;
   FLASH_STAMP(stamp_start);
@@ -388,14 +418,14 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   lds_char* const k_ring = smem;
   lds_char* const v_ring = smem + kRing * kTileBytes;
 
-  // staging: piece pc = 1 KiB = 4 LDS rows; lane i of it fills chunk i % 16 of row 4 pc + i / 16 with
-  // the source chunk that the swizzle maps there
+  // staging: piece pc = 1 KiB of consecutive LDS chunks; lane i of it fills chunk (64 pc + i) % kChunks
+  // of row (64 pc + i) / kChunks with the source chunk that the swizzle maps there
   uint32_t dma_off[kPiecesPerWave];
 #pragma unroll
   for (int i = 0; i < kPiecesPerWave; ++i) {
     const int ci = (wave * kPiecesPerWave + i) * 64 + lane;
-    const int row = ci / 16;
-    const int src = (ci % 16) ^ swz(row);
+    const int row = ci / C::kChunks;
+    const int src = (ci % C::kChunks) ^ swz<D>(row);
     dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
   }
   auto piece = [&](const srd_t srd, lds_char* ring, int slot, int t, int i) __attribute__((always_inline)) {
@@ -424,7 +454,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     qrow[q] = (int)qt * kBr + wave * kRowsPerWave + q * 16 + n16;
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) {
-      const int col = 8 * (ks + 4 * g);
+      const int col = 8 * (ks + kKS * g);
       const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * 2u : kOob;
       const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
       qf[q][ks] = __builtin_bit_cast(f16x8, raw);
@@ -457,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       asm volatile("" : "+a"(o[q][b]));
     }
   }
-  const LaneAddr la = make_lane_addr(lane, k_ring, v_ring);
+  const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
 
   staged_barrier();
 
@@ -471,7 +501,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     for (int j = 0; j < 8; ++j) pB[q][j] = (f16)0.f;
   }
 #pragma unroll
-  for (int f = 0; f < 4; ++f) ka[f] = read_k(0u, la, f / kKS, f % kKS);
+  for (int f = 0; f < 4; ++f) ka[f] = read_k<D>(0u, la, f / kKS, f % kKS);
 #pragma unroll
   for (int f = 0; f < 2 * kKS; ++f) {
 #pragma unroll
@@ -483,9 +513,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       }
     }
     if (f + 4 < 2 * kKS) {
-      ka[f % 4] = read_k(0u, la, (f + 4) / kKS, (f + 4) % kKS);
+      ka[f % 4] = read_k<D>(0u, la, (f + 4) / kKS, (f + 4) % kKS);
     } else {
-      ka[f % 4] = read_k((uint32_t)kBlkBytes, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
+      ka[f % 4] = read_k<D>((uint32_t)kBlkBytes, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
     }
   }
   drain_s(sA);
@@ -522,7 +552,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     auto no_hook = [](int) __attribute__((always_inline)) {};
     // staging spread over the slots of the first step: K tile t+2, then V tile t+1
     auto dma_hook = [&](int n) __attribute__((always_inline)) {
-      constexpr int kSpacing = 64 / (2 * kPiecesPerWave);
+      constexpr int kSpacing = (2 * kKS + kDv16) * kQ16 / (2 * kPiecesPerWave);
       if (n % kSpacing == 1) {
         const int i = n / kSpacing;
         if (i < kPiecesPerWave) {
@@ -536,12 +566,12 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const uint32_t k_nxt = (uint32_t)(s1 * kTileBytes);
     const uint32_t v_cur = (uint32_t)(s0 * kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * kTileBytes);
-    pipeline_step<true, !LAST, MASKED>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
+    pipeline_step<D, true, !LAST, MASKED>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
                                        pB, pA, st, t * kBc + 32, N, lane);
-    step_end<true>(o, st, bias, sB, pending, lane);
-    pipeline_step<!LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
+    step_end<kDv16, true>(o, st, bias, sB, pending, lane);
+    pipeline_step<D, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
                                         (t + 1) * kBc, N, lane);
-    step_end<!LAST>(o, st, bias, sA, pending, lane);
+    step_end<kDv16, !LAST>(o, st, bias, sA, pending, lane);
     staged_barrier();
   };
   using std::integral_constant;
@@ -562,7 +592,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const uint32_t vb = (uint32_t)(((nt - 1) % 3) * kTileBytes + kBlkBytes);
 #pragma unroll
     for (int b = 0; b < kDv16; ++b) {
-      const f16x8 vf = read_v(vb, la, b);
+      const f16x8 vf = read_v<D>(vb, la, b);
 #pragma unroll
       for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
     }

@@ -86,10 +86,11 @@ int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
   return launch_kernel(attn_fwd_kernel<D, T, FAST>, prm, lds, stream, attr_done);
 }
 
-// head-dim tile 128, fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel
+// fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel
+template <int D>
 int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
   static thread_local bool attr_done[16] = {};
-  return launch_kernel(m16::attn_fwd_kernel_m16, prm, lds, stream, attr_done);
+  return launch_kernel(m16::attn_fwd_kernel_m16<D>, prm, lds, stream, attr_done);
 }
 
 template <typename Kernel>
@@ -160,11 +161,12 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   hipStream_t stream = (hipStream_t)hip_stream;
   if constexpr (sizeof(T) == 2) {
     if (plan.fast) {
-#if defined(FLASH_D128_MFMA32)
+#if defined(FLASH_MFMA32)  // comparison builds: the 32x32x16 kernel on the fast path as well
       return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
 #else
-      static_assert(m16::kLdsBytes == Geom<128>::kLdsBytes, "both 128-wide kernels use the same LDS rings");
-      return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch_m16(prm, plan.lds, stream);
+      static_assert(m16::Cfg<128>::kLdsBytes == Geom<128>::kLdsBytes && m16::Cfg<64>::kLdsBytes == Geom<64>::kLdsBytes,
+                    "both kernel families use the same LDS rings");
+      return plan.tile_d == 64 ? launch_m16<64>(prm, plan.lds, stream) : launch_m16<128>(prm, plan.lds, stream);
 #endif
     }
   }

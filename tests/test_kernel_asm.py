@@ -64,9 +64,9 @@ def test_no_kernel_spills(asm_text):
 
 
 TUNED = {
-    # kernel-name fragment -> MFMAs per unrolled triple of tile iterations (6 steps)
-    "attn_fwd_kernel_m16": 6 * 64,               # d=128 tile on 16x16x32: 32 QK + 32 PV per step
-    "attn_fwd_kernelILi64EDF16_Lb1": 6 * 18,     # d=64 tile on 32x32x16: 2 bias + 8 QK + 8 PV per step
+    # kernel-name fragment -> MFMAs per unrolled triple of tile iterations (6 steps of 16x16x32 MFMAs)
+    "attn_fwd_kernel_m16ILi128E": 6 * 64,   # d=128 tile: 32 QK + 32 PV per step
+    "attn_fwd_kernel_m16ILi64E": 6 * 32,    # d=64 tile: 16 QK + 16 PV per step
 }
 
 
