@@ -334,6 +334,12 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
   group_add(ELEMS / 4 - 1);
 }
 
+// The bias registers are written by the vector ALU and read as srcC by MFMAs that the compiler does not
+// recognise as such: the wait states between the two are provided here, tied to the registers.
+__device__ __forceinline__ void bias_ready(f32x4 (&bias)[kQ16]) {
+  asm volatile("s_nop 4" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]));
+}
+
 // Between two steps: pending O rescale, then the decision whether the next block moves a reference.
 template <int NB, bool HAS_NEXT>
 __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], f32x4 (&bias)[kQ16],
@@ -370,8 +376,7 @@ __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16]
           bias[q][i] = -st[q].mc;
         }
       }
-      // the bias registers are srcC of the next MFMAs
-      asm volatile("s_nop 4" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]));
+      bias_ready(bias);
       pending = true;
     }
   }
@@ -499,6 +504,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) pB[q][j] = (f16)0.f;
+    asm volatile("" : "+v"(pB[q]));  // see the persistent kernel: keeps the zeros from being re-materialised
   }
 #pragma unroll
   for (int f = 0; f < 4; ++f) ka[f] = read_k<D>(0u, la, f / kKS, f % kKS);
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     st[q].alpha = 1.f;
     st[q].mx_next = 0.f;
   }
+  bias_ready(bias);
 
   FLASH_STAMP(stamp_loop);
   auto tile_iter = [&](auto slot_tag, auto masked_tag, auto last_tag, int t, int slot_rt) __attribute__((always_inline)) {
@@ -629,6 +636,330 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   }
   FLASH_STAMP(stamp_end);
   FLASH_STAMP_STORE(p, wave, lane, stamp_start, stamp_loop, stamp_tail, stamp_end);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---- persistent variant ---------------------------------------------------------------------------
+// For N % 256 == 0 (whole query tiles, a K/V tile count that is a multiple of four, no key mask).
+// One workgroup per CU works through a list of (head, query tile) items.  The K/V staging never
+// stops at an item boundary: the rings have four slots, tile t of every item sits in slot t % 4, and
+// the last two tile iterations of an item already stage the first tiles of the next one, so the next
+// item finds K tiles 0, 1 and V tile 0 in LDS.  Its Q is fetched (raw, straight into the
+// accumulation registers that hold Q) while the current item's last P V product and output stores
+// run.  What remains between two items is S(0) of the next item and the conversion of Q; the
+// HBM round trips of a cold prologue are paid once per workgroup instead of once per item.
+constexpr int kRingP = 4;
+
+template <int D>
+struct CfgP : Cfg<D> {
+  static constexpr int kLdsBytes = 2 * kRingP * Cfg<D>::kTileBytes;
+};
+
+// 16 bytes per lane from a raw buffer straight into accumulation registers.  Not tracked by the
+// compiler: the caller waits (s_waitcnt vmcnt) before the registers are used.
+__device__ __forceinline__ void load_q_raw(f16x8& dst, srd_t srd, uint32_t voff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(dst) : "v"(voff), "s"(srd) : "memory");
+}
+
+// Wait for the Q loads: all vector memory operations but the YOUNGER most recent ones.  The registers
+// are operands of the statement: their readers must not be moved in front of the wait.
+template <int YOUNGER, int KS>
+__device__ __forceinline__ void wait_q(f16x8 (&qf)[kQ16][KS]) {
+  static_assert(KS == 2 || KS == 4, "operand lists are written out for these sizes");
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+    if constexpr (KS == 4) {
+      asm volatile("s_waitcnt vmcnt(%4)"
+                   : "+a"(qf[q][0]), "+a"(qf[q][1]), "+a"(qf[q][2]), "+a"(qf[q][3])
+                   : "n"(YOUNGER)
+                   : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%2)" : "+a"(qf[q][0]), "+a"(qf[q][1]) : "n"(YOUNGER) : "memory");
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using C = CfgP<D>;
+  constexpr int kKS = C::kKS, kDv16 = C::kDv16, kTileBytes = C::kTileBytes, kBlkBytes = C::kBlkBytes;
+  constexpr int kPiecesPerWave = C::kPiecesPerWave;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  lds_char* const smem = (lds_char*)smem_raw;
+
+  // Items are dealt to the 8 XCDs in contiguous ranges (workgroup ids equal mod 8 share an XCD);
+  // the workgroups of an XCD take the items of its range round-robin, so at any time they work on
+  // neighbouring query tiles of the same few heads and share their K/V through the XCD's L2.
+  const uint32_t bid = blockIdx.x;
+  const uint32_t xcd = bid & 7u, slot_id = bid >> 3;
+  const uint32_t wgs_on_xcd = (gridDim.x - xcd + 7u) >> 3;
+  const uint32_t per = p.total_wg >> 3, rem = p.total_wg & 7u;
+  const uint32_t lo = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
+  const uint32_t hi = lo + per + (xcd < rem ? 1u : 0u);
+  uint32_t item = lo + slot_id;
+  if (item >= hi) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15;
+  const int g = lane >> 4;
+  const int N = p.N, d = p.d;
+  const int nt = N / kBc;  // multiple of 4
+
+  const size_t head_elems = (size_t)N * (size_t)d;
+  const uint32_t head_bytes = (uint32_t)(head_elems * 2);
+  const uint32_t row_bytes = (uint32_t)d * 2u;
+  const uint32_t tile_step = (uint32_t)kBc * row_bytes;
+
+  lds_char* const k_ring = smem;
+  lds_char* const v_ring = smem + kRingP * kTileBytes;
+
+  uint32_t dma_off[kPiecesPerWave];
+#pragma unroll
+  for (int i = 0; i < kPiecesPerWave; ++i) {
+    const int ci = (wave * kPiecesPerWave + i) * 64 + lane;
+    const int row = ci / C::kChunks;
+    const int src = (ci % C::kChunks) ^ swz<D>(row);
+    dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
+  }
+  auto piece = [&](const srd_t srd, lds_char* ring, int slot, int t, int i) __attribute__((always_inline)) {
+    const int pc = wave * kPiecesPerWave + i;
+    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + slot * kTileBytes + pc * 1024));
+    dma_piece(srd, dma_off[i] + (uint32_t)t * tile_step, lds_base);
+  };
+  auto staged_barrier = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  auto head_of = [&](uint32_t it) __attribute__((always_inline)) { return it / (uint32_t)p.nqt; };
+
+  // per-lane byte offsets of the Q chunks inside a head, for query tile 0 (a tile adds kBr rows)
+  uint32_t q_off[kQ16][kKS];
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) {
+      const int col = 8 * (ks + kKS * g);
+      const uint32_t row = (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
+      q_off[q][ks] = (col < d) ? (row * (uint32_t)d + (uint32_t)col) * 2u : kOob;
+    }
+  }
+  const uint32_t q_tile_bytes = (uint32_t)kBr * row_bytes;
+
+  f16x8 qf[kQ16][kKS];
+  auto fetch_q = [&](uint32_t it) __attribute__((always_inline)) {
+    const uint32_t hd = head_of(it), qt = it - hd * (uint32_t)p.nqt;
+    const srd_t q_srd = make_srd((const f16*)p.q + (size_t)hd * head_elems, head_bytes);
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+      for (int ks = 0; ks < kKS; ++ks) {
+        // a chunk beyond d keeps its out-of-range offset: adding the tile offset cannot wrap below kOob
+        load_q_raw(qf[q][ks], q_srd, q_off[q][ks] + qt * q_tile_bytes);
+      }
+    }
+  };
+  // pre-multiply by softmax_scale * log2(e); the registers come back as accumulation registers
+  auto convert_q = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+      for (int ks = 0; ks < kKS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
+        asm volatile("" : "+a"(qf[q][ks]));
+      }
+    }
+  };
+
+  // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
+  srd_t k_srd = make_srd((const f16*)p.k + (size_t)head_of(item) * head_elems, head_bytes);
+  srd_t v_srd = make_srd((const f16*)p.v + (size_t)head_of(item) * head_elems, head_bytes);
+  fetch_q(item);
+#pragma unroll
+  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, k_ring, 0, 0, i);
+#pragma unroll
+  for (int i = 0; i < kPiecesPerWave; ++i) piece(v_srd, v_ring, 0, 0, i);
+#pragma unroll
+  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, k_ring, 1, 1, i);
+  // Step 0 of an item multiplies P(-1) = 0 with the second block of "V tile -1" (slot 3): later items
+  // find the previous item's last tile there, the first one needs something finite.
+  for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
+    *FLASH_LDS_CAST(u32x4, v_ring + 3 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
+  }
+  const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
+  wait_q<0>(qf);
+  convert_q();
+  __syncthreads();
+
+  f32x4 o[kQ16][kDv16];
+  f32x4 sA[2][kQ16], sB[2][kQ16];
+  f16x8 pA[kQ16], pB[kQ16];
+  f16x8 ka[4];
+  State st[kQ16];
+  f32x4 bias[kQ16];
+
+  for (;;) {
+    const uint32_t next_item = item + wgs_on_xcd;
+    const bool has_next = next_item < hi;
+    const uint32_t next_head = has_next ? head_of(next_item) : head_of(item);
+    const srd_t k_srd_n = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
+    const srd_t v_srd_n = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);
+    const uint32_t head = head_of(item), qt = item - head * (uint32_t)p.nqt;
+    f16* oh = (f16*)p.o + (size_t)head * head_elems;
+    const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
+
+    // ---- item prologue: O = 0, P(-1) = 0, S(0) and its row max ------------------------------------------
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+      for (int b = 0; b < kDv16; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[q][b][i] = 0.f;
+        asm volatile("" : "+a"(o[q][b]));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pB[q][j] = (f16)0.f;
+      // opaque from here on: a constant would be re-materialised right in front of the MFMA that
+      // reads it, too close for an instruction the compiler does not know to be an MFMA
+      asm volatile("" : "+v"(pB[q]));
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ka[f] = read_k<D>(0u, la, f / kKS, f % kKS);
+#pragma unroll
+    for (int f = 0; f < 2 * kKS; ++f) {
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) {
+        if (f % kKS == 0) {
+          mfma_s_first0(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+        } else {
+          mfma_s<true>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+        }
+      }
+      if (f + 4 < 2 * kKS) {
+        ka[f % 4] = read_k<D>(0u, la, (f + 4) / kKS, (f + 4) % kKS);
+      } else {
+        ka[f % 4] = read_k<D>((uint32_t)kBlkBytes, la, (f + 4 - 2 * kKS) / kKS, (f + 4) % kKS);
+      }
+    }
+    drain_s(sA);
+    bool pending = false;
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+      float mx = fmaxf(fmaxf(sA[0][q][0], sA[0][q][1]), fmaxf(sA[0][q][2], sA[0][q][3]));
+      mx = fmaxf(mx, fmaxf(fmaxf(sA[1][q][0], sA[1][q][1]), fmaxf(sA[1][q][2], sA[1][q][3])));
+      const float mc = quad_lane_max(mx, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sA[0][q][i] -= mc;
+        sA[1][q][i] -= mc;
+        bias[q][i] = -mc;
+      }
+      st[q].mc = mc;
+      st[q].l = 0.f;
+      st[q].alpha = 1.f;
+      st[q].mx_next = 0.f;
+    }
+    bias_ready(bias);
+
+    // ---- tile iterations; SLOT = t % 4 is a compile-time constant -------------------------------------
+    auto tile_iter = [&](auto slot_tag, auto last_tag, int t) __attribute__((always_inline)) {
+      constexpr int S0 = decltype(slot_tag)::value;
+      constexpr bool LAST = decltype(last_tag)::value;
+      constexpr int S1 = (S0 + 1) % 4, S2 = (S0 + 2) % 4, S3 = (S0 + 3) % 4;
+      // the stream continues into the next item: K tile t+2 and V tile t+1 may be its first tiles
+      const bool k_cur_item = t + 2 < nt, v_cur_item = t + 1 < nt;
+      const srd_t ks_srd = k_cur_item ? k_srd : k_srd_n;
+      const srd_t vs_srd = v_cur_item ? v_srd : v_srd_n;
+      const int k_tile = k_cur_item ? t + 2 : t + 2 - nt;
+      const int v_tile = v_cur_item ? t + 1 : t + 1 - nt;
+      const bool k_go = k_cur_item || has_next, v_go = v_cur_item || has_next;
+      auto no_hook = [](int) __attribute__((always_inline)) {};
+      auto dma_hook = [&](int n) __attribute__((always_inline)) {
+        constexpr int kSpacing = (2 * kKS + kDv16) * kQ16 / (2 * kPiecesPerWave);
+        if (n % kSpacing == 1) {
+          const int i = n / kSpacing;
+          if (i < kPiecesPerWave) {
+            if (k_go) piece(ks_srd, k_ring, S2, k_tile, i);
+          } else if (i < 2 * kPiecesPerWave) {
+            if (v_go) piece(vs_srd, v_ring, S1, v_tile, i - kPiecesPerWave);
+          }
+        }
+      };
+      constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
+      constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
+      pipeline_step<D, true, !LAST, false>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA,
+                                           sB, pB, pA, st, 0, N, lane);
+      step_end<kDv16, true>(o, st, bias, sB, pending, lane);
+      pipeline_step<D, !LAST, !LAST, false>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB,
+                                            st, 0, N, lane);
+      step_end<kDv16, !LAST>(o, st, bias, sA, pending, lane);
+      staged_barrier();
+    };
+    using std::integral_constant;
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+    tile_iter(integral_constant<int, 0>{}, no, 0);
+    tile_iter(integral_constant<int, 1>{}, no, 1);
+    tile_iter(integral_constant<int, 2>{}, no, 2);
+    for (int t = 3; t + 1 < nt; t += 4) {
+      tile_iter(integral_constant<int, 3>{}, no, t);
+      tile_iter(integral_constant<int, 0>{}, no, t + 1);
+      tile_iter(integral_constant<int, 1>{}, no, t + 2);
+      tile_iter(integral_constant<int, 2>{}, no, t + 3);
+    }
+    tile_iter(integral_constant<int, 3>{}, yes, nt - 1);
+
+    // Q is dead: fetch the next item's (the loads land while the last P V product and the stores run)
+    if (has_next) fetch_q(next_item);
+
+    // ---- P V of the last block, epilogue ------------------------------------------------------------------
+    {
+      drain_o(o);
+      constexpr uint32_t vb = (uint32_t)(3 * kTileBytes + kBlkBytes);
+#pragma unroll
+      for (int b = 0; b < kDv16; ++b) {
+        const f16x8 vf = read_v<D>(vb, la, b);
+#pragma unroll
+        for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
+      }
+      drain_o(o);
+    }
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) {
+      const float inv = 1.0f / quad_lane_sum(st[q].l, lane);
+      const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
+#pragma unroll
+      for (int b = 0; b < kDv16; b += 2) {
+        f16x4 x, y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          x[j] = (f16)(o[q][b][j] * inv);
+          y[j] = (f16)(o[q][b + 1][j] * inv);
+        }
+        const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+        u32x4 out;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          auto r = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
+          out[w] = r[0];
+          out[2 + w] = r[1];
+        }
+        const int dv = 16 * (b + (g & 1)) + 8 * (g >> 1);
+        const uint32_t off = (dv < d) ? (qrow * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
+        __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
+      }
+    }
+    if (!has_next) break;
+    // the Q loads are older than this item's output stores: wait for everything but those stores
+    wait_q<kQ16 * kDv16 / 2>(qf);
+    convert_q();
+    item = next_item;
+    k_srd = k_srd_n;
+    v_srd = v_srd_n;
+  }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "attn_fwd_mfma.hpp"
 #include "attn_fwd_mfma16.hpp"
 #if defined(FLASH_PHASE_STAMPS)
@@ -77,24 +79,11 @@ int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool 
   return FLASH_HIP_OK;
 }
 
-template <typename Kernel>
-int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16]);
-
-template <int D, typename T, bool FAST>
-int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
-  static thread_local bool attr_done[16] = {};
-  return launch_kernel(attn_fwd_kernel<D, T, FAST>, prm, lds, stream, attr_done);
-}
-
-// fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel
-template <int D>
-int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
-  static thread_local bool attr_done[16] = {};
-  return launch_kernel(m16::attn_fwd_kernel_m16<D>, prm, lds, stream, attr_done);
-}
 
 template <typename Kernel>
-int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16]) {
+int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16],
+                  uint32_t grid = 0) {
+  if (grid == 0) grid = prm.total_wg;
   // Above the 64 KiB default a kernel must opt in to its dynamic LDS size (the reference does the
   // same above 48 KiB, launch.cu:134-148).
   int dev = 0;
@@ -118,7 +107,7 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
     (void)hipMemsetAsync(buf, 0, n * 8, stream);
     FwdParams prm2 = prm;
     prm2.stamps = buf;
-    hipLaunchKernelGGL(kern, dim3(prm.total_wg), dim3(kThreads), lds, stream, prm2);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, prm2);
     (void)hipStreamSynchronize(stream);
     std::vector<unsigned long long> h(n);
     (void)hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost);
@@ -134,11 +123,60 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
               ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, cnt);
   }
 #else
-  hipLaunchKernelGGL(kern, dim3(prm.total_wg), dim3(kThreads), lds, stream, prm);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, prm);
 #endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
   return FLASH_HIP_OK;
+}
+
+template <int D, typename T, bool FAST>
+int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
+  static thread_local bool attr_done[16] = {};
+  return launch_kernel(attn_fwd_kernel<D, T, FAST>, prm, lds, stream, attr_done);
+}
+
+// fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel
+template <int D>
+int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
+  static thread_local bool attr_done[16] = {};
+  return launch_kernel(m16::attn_fwd_kernel_m16<D>, prm, lds, stream, attr_done);
+}
+
+// FLASH_HIP_PERSISTENT=0 in the environment routes whole-tile shapes to the one-item-per-workgroup
+// kernel as well (for A/B measurements; read on every call so that a harness can flip it).
+static bool use_persistent() {
+  const char* e = getenv("FLASH_HIP_PERSISTENT");
+  return !(e && e[0] == '0');
+}
+
+// Longest sequence routed to the persistent kernel (FLASH_HIP_PERSISTENT_MAX_N overrides, for A/B runs).
+static int64_t persistent_max_n() {
+  const char* e = getenv("FLASH_HIP_PERSISTENT_MAX_N");
+  return e ? atoll(e) : 1024;
+}
+
+// Workgroups of the persistent kernel: one per CU (the kernel needs a CU's whole register file and
+// most of its LDS), never more than there are items.
+static uint32_t persistent_grid(uint32_t items) {
+  static thread_local int cus[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus[dev] = n;
+  }
+  const uint32_t g = (uint32_t)cus[dev] & ~7u;  // a multiple of the 8 XCDs
+  return items < g ? items : (g ? g : 8u);
+}
+
+// whole query tiles (N % 256 == 0): persistent workgroups with uninterrupted K/V staging
+template <int D>
+int launch_m16p(const FwdParams& prm, hipStream_t stream) {
+  static thread_local bool attr_done[16] = {};
+  return launch_kernel(m16::attn_fwd_kernel_m16p<D>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream, attr_done,
+                       persistent_grid(prm.total_wg));
 }
 
 template <typename T>
@@ -166,6 +204,10 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
 #else
       static_assert(m16::Cfg<128>::kLdsBytes == Geom<128>::kLdsBytes && m16::Cfg<64>::kLdsBytes == Geom<64>::kLdsBytes,
                     "both kernel families use the same LDS rings");
+      // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab): +4..5 % up to
+      // N = 1024, where the cold prologue is a fifth of an item, -2 % from N = 2048 on.
+      if (N % kBr == 0 && N <= persistent_max_n() && use_persistent())
+        return plan.tile_d == 64 ? launch_m16p<64>(prm, stream) : launch_m16p<128>(prm, stream);
       return plan.tile_d == 64 ? launch_m16<64>(prm, plan.lds, stream) : launch_m16<128>(prm, plan.lds, stream);
 #endif
     }

@@ -229,7 +229,57 @@ static int bench_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps, int
   return ok ? 0 : 1;
 }
 
+// A/B of the persistent and the one-item-per-workgroup kernels, interleaved launch by launch in one
+// process on one device (FLASH_HIP_PERSISTENT is read by the library on every call).
+static int ab_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps) {
+  const size_t n = (size_t)(B * H * N * d);
+  std::vector<float> x(std::min<size_t>(n, (size_t)8 * N * d));
+  fill_normal(x);
+  std::vector<uint16_t> xh(x.size());
+  oracle_f32_to_f16_bits(x.data(), xh.data(), x.size());
+  uint16_t *dq, *dk, *dv, *dout;
+  HIP_CHECK(hipMalloc(&dq, n * 2));
+  HIP_CHECK(hipMalloc(&dk, n * 2));
+  HIP_CHECK(hipMalloc(&dv, n * 2));
+  HIP_CHECK(hipMalloc(&dout, n * 2));
+  for (size_t off = 0; off < n; off += xh.size()) {
+    const size_t len = std::min(xh.size(), n - off);
+    HIP_CHECK(hipMemcpy(dq + off, xh.data(), len * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dk + off, xh.data() + (xh.size() - len) / 2, len * 2, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dv + off, xh.data(), len * 2, hipMemcpyHostToDevice));
+  }
+  const float scale = 1.0f / std::sqrt((float)d);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  std::vector<float> t[2];
+  setenv("FLASH_HIP_PERSISTENT_MAX_N", "1000000000", 1);  // let the switch below decide alone
+  for (int i = 0; i < 2 * (reps + 3); ++i) {
+    const int which = i & 1;
+    setenv("FLASH_HIP_PERSISTENT", which ? "1" : "0", 1);
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, FLASH_KT_MMA_QREG_ASYNC, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (i >= 6) t[which].push_back(ms);
+  }
+  const double flops = 4.0 * B * H * (double)N * (double)N * d;
+  for (int which = 0; which < 2; ++which) {
+    std::sort(t[which].begin(), t[which].end());
+    const double med = t[which][t[which].size() / 2];
+    printf("ab (%lld,%lld,%lld,%lld) %s: median %.4f ms -> %.1f TFLOP/s, best %.1f\n", (long long)B, (long long)H,
+           (long long)N, (long long)d, which ? "persistent      " : "item-per-workgroup", med, flops / med * 1e-9,
+           flops / t[which][0] * 1e-9);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 6 && std::string(argv[1]) == "ab") {
+    return ab_shape(atoll(argv[2]), atoll(argv[3]), atoll(argv[4]), atoll(argv[5]), argc > 6 ? atoi(argv[6]) : 30);
+  }
   if (argc >= 6 && std::string(argv[1]) == "bench") {
     const int reps = argc > 6 ? atoi(argv[6]) : 20;
     const int kt = argc > 7 ? atoi(argv[7]) : FLASH_KT_MMA_QREG_ASYNC;
