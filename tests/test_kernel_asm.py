@@ -37,7 +37,8 @@ def kernels(asm_text):
 
 
 def main_loop(lines):
-    """Instruction lines of the innermost loop that holds at least 90 MFMAs (the unrolled tile triple)."""
+    """Instruction lines of the smallest loop that holds at least 90 MFMAs (the unrolled tile group)."""
+    best = None
     for i, l in enumerate(lines):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if not m:
@@ -46,10 +47,10 @@ def main_loop(lines):
         for j in range(i + 1, len(lines)):
             if re.search(r"s_cbranch_\w+\s+" + re.escape(lab) + r"\b", lines[j]):
                 body = lines[i:j + 1]
-                if sum("v_mfma" in x for x in body) >= 90:
-                    return body
+                if sum("v_mfma" in x for x in body) >= 90 and (best is None or len(body) < len(best)):
+                    best = body
                 break
-    return None
+    return best
 
 
 def test_no_kernel_spills(asm_text):
