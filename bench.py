@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel-type", default="mma_qreg_async")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL; gloo lets several ranks rehearse the "
+                         "multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import torch
@@ -110,11 +113,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path for the attention kernel")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({n_dev} visible)")
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     shape = WORKLOADS[args.workload]
     B, H, N, d = shape
@@ -144,7 +153,7 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -1,6 +1,11 @@
 // FlashAttention-2 forward for gfx950 (MI355X, CDNA4): fp16 operands on
 // v_mfma_f32_32x32x16_f16, fp32 accumulation, wave64.
 //
+// This is the general kernel of the library: it serves fp32 callers and head dims that are not a
+// multiple of 8 halves (element-wise staging, FAST = false).  fp16 tensors with d % 8 == 0 run on
+// the 16x16x32 kernels of attn_fwd_mfma16.hpp, which share this file's staging, descriptor and
+// softmax helpers; building with -DFLASH_MFMA32 routes them here too (FAST = true) for comparison.
+//
 // Functional counterpart of the reference's kernel_mma_qreg family
 // (reference flash/kernel_mma_qreg.cuh:16-267, kernel_mma_qreg_f32x4load.cuh,
 // kernel_mma_qreg_async.cuh): one workgroup owns a tile of Q rows of one (batch, head), keeps Q in
