@@ -91,6 +91,16 @@ __device__ __forceinline__ void mfma_o(f32x4& acc, const f16x8& a, const f16x8& 
   }
 }
 
+// Row sums on the matrix pipe: v_mfma_f32_4x4x4_16b_f16 computes, for 16 independent 4x4 blocks,
+// D[i][j] = sum_k A[i][k] B[k][j] + C[i][j], where a lane holds the four k-values of one column j of B
+// and gets D[0..3][j] in its four result registers.  With A = all ones every D[i][j] of a lane is the
+// sum of the lane's own four fp16 values, accumulated in fp32: one 2-pass MFMA replaces the vector adds
+// of four probabilities, exactly.
+typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mfma_rowsum(f32x4& acc, const f16x4v& ones, const f16x4v& p4) {
+  asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(ones), "v"(p4));
+}
+
 // Wait states for the last MFMAs, with the accumulators as operands so that their readers stay
 // behind the wait.  The statements are volatile, hence ordered among themselves: the first one
 // carries the wait, the others only tie the remaining registers to that order.
@@ -176,7 +186,6 @@ __device__ __forceinline__ f16x8 read_v(uint32_t voff, const LaneAddr<D>& la, in
 
 struct State {
   float mc;       // reference, exp2 units, of the lane's query in this query block
-  float l;        // partial row sum over this lane's keys
   float alpha;    // pending O factor
   float mx_next;  // max of the next block's relative scores over this lane's keys
 };
@@ -199,7 +208,8 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
                                               const f16x8 (&qf)[kQ16][Cfg<D>::kKS], f16x8 (&ka)[4],
                                               f32x4 (&o)[kQ16][Cfg<D>::kDv16], const f32x4 (&s_cur)[2][kQ16],
                                               f32x4 (&s_nxt)[2][kQ16], const f16x8 (&p_prev)[kQ16],
-                                              f16x8 (&p_cur)[kQ16], State (&st)[kQ16], int kv_next0, int N, int lane) {
+                                              f16x8 (&p_cur)[kQ16], State (&st)[kQ16], f32x4 (&lsum)[kQ16],
+                                              int kv_next0, int N, int lane) {
   constexpr int kKS = Cfg<D>::kKS, kDv16 = Cfg<D>::kDv16;
   constexpr int QK_SLOTS = 2 * kKS * kQ16;  // 32 (D = 128), 16 (D = 64)
   constexpr int PV_SLOTS = kDv16 * kQ16;    // 32, 16
@@ -215,26 +225,29 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
 
   // exp(j), software-pipelined over the slots.  Element g = 8q + e: key block e / 4, register e % 4.
   float t_exp = 0.f, t_exp_prev = 0.f;
-  f16x2 pk[2], ps, one2;
-  one2[0] = one2[1] = (f16)1.f;
+  f16x4v ones4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ones4[j] = (f16)1.f;
+  asm volatile("" : "+v"(ones4));
   auto pin = [](f16x2& x) __attribute__((always_inline)) {
     uint32_t w = __builtin_bit_cast(uint32_t, x);
     asm volatile("" : "+v"(w));
     x = __builtin_bit_cast(f16x2, w);
   };
-  auto group_sum = [&]() __attribute__((always_inline)) {
-    ps = pk[0] + pk[1];
-    pin(ps);
-  };
+  // row sum of the four probabilities packed two elements ago: half `hf` of query block q's fragment
   auto group_add = [&](int group) __attribute__((always_inline)) {
-    float& l = st[group / 2].l;
-    l = __builtin_amdgcn_fdot2(ps, one2, l, false);
-    asm volatile("" : "+v"(l));
+    const int q = group / 2, hf = group % 2;
+    f16x4v p4;
+    if (hf == 0) {
+      p4 = __builtin_shufflevector(p_cur[q], p_cur[q], 0, 1, 2, 3);
+    } else {
+      p4 = __builtin_shufflevector(p_cur[q], p_cur[q], 4, 5, 6, 7);
+    }
+    mfma_rowsum(lsum[q], ones4, p4);
   };
   auto finish = [&](int g) __attribute__((always_inline)) {
     const int q = g / 8, e = g % 8;
-    if ((g & 3) == 0 && g >= 4) group_sum();
-    if ((g & 3) == 2 && g >= 6) group_add(g / 4 - 1);
+    if ((g & 3) == 1 && g >= 5) group_add(g / 4 - 1);
     if ((g & 1) != 0) {
       f16x2 w;
       w[0] = (f16)t_exp_prev;
@@ -242,7 +255,6 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
       pin(w);
       p_cur[q][e - 1] = w[0];
       p_cur[q][e] = w[1];
-      pk[(g >> 1) & 1] = w;
     }
     t_exp_prev = t_exp;
   };
@@ -330,8 +342,13 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     }
   }
   finish(ELEMS - 1);
-  group_sum();
+  asm volatile("s_nop 1" ::: "memory");  // the last pair was packed by the instruction just before
   group_add(ELEMS / 4 - 1);
+}
+
+// Wait states before the row sums are read by anything but the MFMA that accumulates them.
+__device__ __forceinline__ void drain_lsum(f32x4 (&lsum)[kQ16]) {
+  asm volatile("s_nop 7" : "+a"(lsum[0]), "+a"(lsum[1]), "+a"(lsum[2]), "+a"(lsum[3]));
 }
 
 // The bias registers are written by the vector ALU and read as srcC by MFMAs that the compiler does not
@@ -342,8 +359,8 @@ __device__ __forceinline__ void bias_ready(f32x4 (&bias)[kQ16]) {
 
 // Between two steps: pending O rescale, then the decision whether the next block moves a reference.
 template <int NB, bool HAS_NEXT>
-__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], f32x4 (&bias)[kQ16],
-                                         f32x4 (&s_nxt)[2][kQ16], bool& pending, int lane) {
+__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], f32x4 (&lsum)[kQ16],
+                                         f32x4 (&bias)[kQ16], f32x4 (&s_nxt)[2][kQ16], bool& pending, int lane) {
   bool any_need = false;
   if constexpr (HAS_NEXT) {
     const float mxx = fmaxf(fmaxf(st[0].mx_next, st[1].mx_next), fmaxf(st[2].mx_next, st[3].mx_next));
@@ -363,12 +380,14 @@ __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16]
     }
     pending = false;
     if (any_need) {
+      drain_lsum(lsum);
 #pragma unroll
       for (int q = 0; q < kQ16; ++q) {
         const float rise = fmaxf(quad_lane_max(st[q].mx_next, lane), 0.f);  // references only move up
         st[q].alpha = fast_exp2(-rise);
         st[q].mc += rise;
-        st[q].l *= st[q].alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lsum[q][i] *= st[q].alpha;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           s_nxt[0][q][i] -= rise;
@@ -527,6 +546,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   drain_s(sA);
   State st[kQ16];
   f32x4 bias[kQ16];
+  f32x4 lsum[kQ16];  // row sums, every register of a lane holds the same partial sum (see mfma_rowsum)
   bool pending = false;
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {
@@ -542,7 +562,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       bias[q][i] = -mc;
     }
     st[q].mc = mc;
-    st[q].l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lsum[q][i] = 0.f;
+    asm volatile("" : "+a"(lsum[q]));
     st[q].alpha = 1.f;
     st[q].mx_next = 0.f;
   }
@@ -574,11 +596,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const uint32_t v_cur = (uint32_t)(s0 * kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * kTileBytes);
     pipeline_step<D, true, !LAST, MASKED>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
-                                       pB, pA, st, t * kBc + 32, N, lane);
-    step_end<kDv16, true>(o, st, bias, sB, pending, lane);
+                                       pB, pA, st, lsum, t * kBc + 32, N, lane);
+    step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
     pipeline_step<D, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
-                                        (t + 1) * kBc, N, lane);
-    step_end<kDv16, !LAST>(o, st, bias, sA, pending, lane);
+                                        lsum, (t + 1) * kBc, N, lane);
+    step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
     staged_barrier();
   };
   using std::integral_constant;
@@ -604,6 +626,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
     }
     drain_o(o);
+    drain_lsum(lsum);
   }
 
   // ---- epilogue: O = O^T / l.  Tile b of query block q holds dv = 16b + 4g + 0..3 of the lane's query.
@@ -611,7 +634,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   // consecutive columns of one of them and writes one 128-bit store.
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {
-    const float inv = 1.0f / quad_lane_sum(st[q].l, lane);
+    const float inv = 1.0f / quad_lane_sum(lsum[q][0], lane);
 #pragma unroll
     for (int b = 0; b < kDv16; b += 2) {
       f16x4 x, y;
@@ -800,6 +823,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   f16x8 ka[4];
   State st[kQ16];
   f32x4 bias[kQ16];
+  f32x4 lsum[kQ16];
 
   for (;;) {
     const uint32_t next_item = item + wgs_on_xcd;
@@ -858,7 +882,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         bias[q][i] = -mc;
       }
       st[q].mc = mc;
-      st[q].l = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lsum[q][i] = 0.f;
+      asm volatile("" : "+a"(lsum[q]));
       st[q].alpha = 1.f;
       st[q].mx_next = 0.f;
     }
@@ -891,11 +917,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
       constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
       pipeline_step<D, true, !LAST, false>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA,
-                                           sB, pB, pA, st, 0, N, lane);
-      step_end<kDv16, true>(o, st, bias, sB, pending, lane);
+                                           sB, pB, pA, st, lsum, 0, N, lane);
+      step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
       pipeline_step<D, !LAST, !LAST, false>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB,
-                                            st, 0, N, lane);
-      step_end<kDv16, !LAST>(o, st, bias, sA, pending, lane);
+                                            st, lsum, 0, N, lane);
+      step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
       staged_barrier();
     };
     using std::integral_constant;
@@ -926,10 +952,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
       }
       drain_o(o);
+      drain_lsum(lsum);
     }
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
-      const float inv = 1.0f / quad_lane_sum(st[q].l, lane);
+      const float inv = 1.0f / quad_lane_sum(lsum[q][0], lane);
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
 #pragma unroll
       for (int b = 0; b < kDv16; b += 2) {
