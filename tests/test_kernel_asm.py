@@ -81,7 +81,7 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
     lines = next(iter(ks.values()))
     loop = main_loop(lines)
     assert loop is not None, "main loop not found"
-    n_mfma = sum("v_mfma" in l for l in loop)
+    n_mfma = sum("v_mfma_f32_16x16x32" in l for l in loop)   # the 4x4x4 row-sum MFMAs come on top
     per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
     assert n_mfma in (TUNED[frag][0], TUNED[frag][0] - per_step), n_mfma
     if "m16p" in frag:
