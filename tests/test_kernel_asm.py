@@ -36,8 +36,9 @@ def kernels(asm_text):
     return out
 
 
-def main_loop(lines):
-    """Instruction lines of the smallest loop that holds at least 90 MFMAs (the unrolled tile group)."""
+def main_loop(lines, min_mfma=90):
+    """Instruction lines of the smallest loop that holds at least `min_mfma` 16x16x32 MFMAs (the unrolled
+    tile group; the tail loops with run-time ring slots hold a single tile)."""
     best = None
     for i, l in enumerate(lines):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
@@ -47,7 +48,7 @@ def main_loop(lines):
         for j in range(i + 1, len(lines)):
             if re.search(r"s_cbranch_\w+\s+" + re.escape(lab) + r"\b", lines[j]):
                 body = lines[i:j + 1]
-                if sum("v_mfma" in x for x in body) >= 90 and (best is None or len(body) < len(best)):
+                if sum("v_mfma_f32_16x16x32" in x for x in body) >= min_mfma and (best is None or len(body) < len(best)):
                     best = body
                 break
     return best
@@ -79,10 +80,10 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
     ks = {n: l for n, l in kernels(asm_text).items() if frag in n}
     assert len(ks) == 1, list(ks)
     lines = next(iter(ks.values()))
-    loop = main_loop(lines)
+    per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
+    loop = main_loop(lines, TUNED[frag][0] - per_step)
     assert loop is not None, "main loop not found"
     n_mfma = sum("v_mfma_f32_16x16x32" in l for l in loop)   # the 4x4x4 row-sum MFMAs come on top
-    per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
     assert n_mfma in (TUNED[frag][0], TUNED[frag][0] - per_step), n_mfma
     if "m16p" in frag:
         # the cold rescale blocks of the persistent kernels are laid out inside the loop's address range,
