@@ -829,8 +829,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const uint32_t next_item = item + wgs_on_xcd;
     const bool has_next = next_item < hi;
     const uint32_t next_head = has_next ? head_of(next_item) : head_of(item);
-    const srd_t k_srd_n = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
-    const srd_t v_srd_n = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);
     const uint32_t head = head_of(item), qt = item - head * (uint32_t)p.nqt;
     f16* oh = (f16*)p.o + (size_t)head * head_elems;
     const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
@@ -891,16 +889,26 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     bias_ready(bias);
 
     // ---- tile iterations; SLOT = t % 4 is a compile-time constant -------------------------------------
-    auto tile_iter = [&](auto slot_tag, auto last_tag, int t) __attribute__((always_inline)) {
+    // CROSS marks the last two tile iterations of an item, whose staging targets (K tile t+2, V tile
+    // t+1) may already be the first tiles of the next item; all others stage from the current head.
+    auto tile_iter = [&](auto slot_tag, auto cross_tag, auto last_tag, int t) __attribute__((always_inline)) {
       constexpr int S0 = decltype(slot_tag)::value;
+      constexpr bool CROSS = decltype(cross_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;
       constexpr int S1 = (S0 + 1) % 4, S2 = (S0 + 2) % 4, S3 = (S0 + 3) % 4;
-      // the stream continues into the next item: K tile t+2 and V tile t+1 may be its first tiles
-      const bool k_cur_item = t + 2 < nt, v_cur_item = t + 1 < nt;
-      const srd_t ks_srd = k_cur_item ? k_srd : k_srd_n;
-      const srd_t vs_srd = v_cur_item ? v_srd : v_srd_n;
-      const int k_tile = k_cur_item ? t + 2 : t + 2 - nt;
-      const int v_tile = v_cur_item ? t + 1 : t + 1 - nt;
+      const bool k_cur_item = !CROSS || t + 2 < nt, v_cur_item = !CROSS || t + 1 < nt;
+      srd_t ks_srd = k_srd, vs_srd = v_srd;
+      int k_tile = t + 2, v_tile = t + 1;
+      if constexpr (CROSS) {
+        if (!k_cur_item) {
+          ks_srd = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
+          k_tile = t + 2 - nt;
+        }
+        if (!v_cur_item) {
+          vs_srd = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);
+          v_tile = t + 1 - nt;
+        }
+      }
       const bool k_go = k_cur_item || has_next, v_go = v_cur_item || has_next;
       auto no_hook = [](int) __attribute__((always_inline)) {};
       auto dma_hook = [&](int n) __attribute__((always_inline)) {
@@ -908,9 +916,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         if (n % kSpacing == 1) {
           const int i = n / kSpacing;
           if (i < kPiecesPerWave) {
-            if (k_go) piece(ks_srd, k_ring, S2, k_tile, i);
+            if (!CROSS || k_go) piece(ks_srd, k_ring, S2, k_tile, i);
           } else if (i < 2 * kPiecesPerWave) {
-            if (v_go) piece(vs_srd, v_ring, S1, v_tile, i - kPiecesPerWave);
+            if (!CROSS || v_go) piece(vs_srd, v_ring, S1, v_tile, i - kPiecesPerWave);
           }
         }
       };
@@ -927,16 +935,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     using std::integral_constant;
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
-    tile_iter(integral_constant<int, 0>{}, no, 0);
-    tile_iter(integral_constant<int, 1>{}, no, 1);
-    tile_iter(integral_constant<int, 2>{}, no, 2);
-    for (int t = 3; t + 1 < nt; t += 4) {
-      tile_iter(integral_constant<int, 3>{}, no, t);
-      tile_iter(integral_constant<int, 0>{}, no, t + 1);
-      tile_iter(integral_constant<int, 1>{}, no, t + 2);
-      tile_iter(integral_constant<int, 2>{}, no, t + 3);
+    tile_iter(integral_constant<int, 0>{}, no, no, 0);
+    tile_iter(integral_constant<int, 1>{}, no, no, 1);
+    for (int t = 2; t + 2 < nt; t += 4) {
+      tile_iter(integral_constant<int, 2>{}, no, no, t);
+      tile_iter(integral_constant<int, 3>{}, no, no, t + 1);
+      tile_iter(integral_constant<int, 0>{}, no, no, t + 2);
+      tile_iter(integral_constant<int, 1>{}, no, no, t + 3);
     }
-    tile_iter(integral_constant<int, 3>{}, yes, nt - 1);
+    tile_iter(integral_constant<int, 2>{}, yes, no, nt - 2);
+    tile_iter(integral_constant<int, 3>{}, yes, yes, nt - 1);
 
     // Q is dead: fetch the next item's (the loads land while the last P V product and the stores run)
     if (has_next) fetch_q(next_item);
@@ -984,8 +992,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     wait_q<kQ16 * kDv16 / 2>(qf);
     convert_q();
     item = next_item;
-    k_srd = k_srd_n;
-    v_srd = v_srd_n;
+    k_srd = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
+    v_srd = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }

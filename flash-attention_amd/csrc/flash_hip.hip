@@ -153,7 +153,7 @@ static bool use_persistent() {
 // Longest sequence routed to the persistent kernel (FLASH_HIP_PERSISTENT_MAX_N overrides, for A/B runs).
 static int64_t persistent_max_n() {
   const char* e = getenv("FLASH_HIP_PERSISTENT_MAX_N");
-  return e ? atoll(e) : 1024;
+  return e ? atoll(e) : (int64_t)1 << 40;
 }
 
 // Workgroups of the persistent kernel: one per CU (the kernel needs a CU's whole register file and
@@ -204,8 +204,8 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
 #else
       static_assert(m16::Cfg<128>::kLdsBytes == Geom<128>::kLdsBytes && m16::Cfg<64>::kLdsBytes == Geom<64>::kLdsBytes,
                     "both kernel families use the same LDS rings");
-      // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab): +4..5 % up to
-      // N = 1024, where the cold prologue is a fifth of an item, -2 % from N = 2048 on.
+      // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
+      // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
       if (N % kBr == 0 && N <= persistent_max_n() && use_persistent())
         return plan.tile_d == 64 ? launch_m16p<64>(prm, stream) : launch_m16p<128>(prm, stream);
       return plan.tile_d == 64 ? launch_m16<64>(prm, plan.lds, stream) : launch_m16<128>(prm, plan.lds, stream);
