@@ -237,7 +237,10 @@ int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type,
   out->tile_kv = kBc;
   out->tile_q = kBr;
   out->tile_d = (uint32_t)plan.tile_d;
-  out->lds_bytes = plan.lds;
+  // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
+  const bool persistent = plan.fast && N % kBr == 0 && N <= persistent_max_n() && use_persistent();
+  out->lds_bytes = !persistent ? plan.lds
+                               : (uint32_t)(plan.tile_d == 64 ? m16::CfgP<64>::kLdsBytes : m16::CfgP<128>::kLdsBytes);
   out->block_x = 64;
   out->block_y = kWaves;
   out->grid_x = (uint32_t)B;

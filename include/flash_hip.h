@@ -64,7 +64,8 @@ typedef struct flash_launch_info {
   uint32_t block_y;      /* waves per workgroup                      (blockDim().y) */
   uint32_t grid_x;       /* B                                        (gridDim().x)  */
   uint32_t grid_y;       /* H                                        (gridDim().y)  */
-  uint32_t grid_z;       /* ceil(N / Br)                             (gridDim().z)  */
+  uint32_t grid_z;       /* ceil(N / Br): grid = the work items; when N % Br == 0 a persistent kernel
+                            walks them with one workgroup per CU      (gridDim().z)  */
   uint32_t staging;      /* 0 = register-staged element loads, 1 = register-staged 128-bit loads,
                             2 = direct global->LDS loads (buffer_load ... lds) */
   uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */

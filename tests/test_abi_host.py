@@ -33,13 +33,13 @@ def test_kernel_type_names_match_reference_order(fa):
 
 
 def test_geometry_query(fa):
-    # GPT-3 head shape: 8 query tiles of 256 rows, 4 waves of 64 lanes (one per SIMD),
-    # 3 K + 3 V tiles of 64 x 128 halves = 96 KiB of LDS
+    # GPT-3 head shape: 8 query tiles of 256 rows, 4 waves of 64 lanes (one per SIMD); whole tiles run on
+    # the persistent kernel: 4 K + 4 V tiles of 64 x 128 halves = 128 KiB of LDS
     info = fa.launch_info(4, 96, 2048, 128, fa.KernelType.mma_qreg_async)
     assert info.tile_size == (64, 256, 128)
     assert info.block_dim == (64, 4)
     assert info.grid_dim == (4, 96, 8)
-    assert info.sram_size == 98304 and info.sram_size <= 160 * 1024
+    assert info.sram_size == 131072 and info.sram_size <= 160 * 1024
     assert info.staging == 2 and info.aligned_rows
     # small heads use the 64-wide tile; ragged N rounds the grid up
     info = fa.launch_info(16, 32, 2049, 64)
