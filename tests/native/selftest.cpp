@@ -292,7 +292,9 @@ int main(int argc, char** argv) {
   // cross tile boundaries of the native kernel (Br = 256, Bc = 64)
   const Shape shapes[] = {{1, 1, 50, 32},  {1, 1, 100, 32},  {1, 1, 64, 50},   {5, 12, 53, 69}, {1, 1, 30, 128},
                           {2, 4, 256, 64}, {2, 3, 300, 128}, {1, 2, 1024, 128}, {3, 2, 577, 64}, {1, 2, 257, 96},
-                          {1, 1, 1, 8},    {1, 3, 129, 40},  {2, 2, 511, 120}};
+                          {1, 1, 1, 8},    {1, 3, 129, 40},  {2, 2, 511, 120},
+                          // whole-tile shapes with item counts that split unevenly over XCDs and workgroups
+                          {3, 7, 512, 64}, {5, 13, 1280, 128}, {1, 5, 256, 128}};
   bool all = true;
   for (const Shape& s : shapes) {
     printf("shape (%lld,%lld,%lld,%lld)\n", (long long)s.B, (long long)s.H, (long long)s.N, (long long)s.d);

@@ -65,6 +65,8 @@ def test_golden_vectors_all_kernel_types(fa, torch_gpu, shape):
 SEEDED = [
     (2, 3, 300, 128), (1, 2, 1024, 128), (3, 2, 577, 64), (1, 2, 257, 96), (1, 1, 1, 8), (1, 3, 129, 40),
     (2, 2, 511, 120), (1, 1, 64, 2), (1, 2, 65, 127), (1, 1, 255, 1), (1, 1, 256, 16), (2, 1, 768, 72),
+    # whole-tile shapes (persistent workgroups): item counts that split unevenly over XCDs / workgroups
+    (3, 7, 512, 64), (5, 13, 1280, 128), (1, 5, 256, 128), (1, 37, 256, 64),
 ]
 
 
