@@ -825,7 +825,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   f32x4 bias[kQ16];
   f32x4 lsum[kQ16];
 
+#if defined(FLASH_PHASE_STAMPS)
+  unsigned long long acc_pro = 0, acc_loop = 0, acc_tail = 0;  // summed over the workgroup's items
+#endif
   for (;;) {
+    FLASH_STAMP(stamp_item);
     const uint32_t next_item = item + wgs_on_xcd;
     const bool has_next = next_item < hi;
     const uint32_t next_head = has_next ? head_of(next_item) : head_of(item);
@@ -889,6 +893,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     bias_ready(bias);
 
     // ---- tile iterations; SLOT = t % 4 is a compile-time constant -------------------------------------
+    FLASH_STAMP(stamp_loop);
     // CROSS marks the last two tile iterations of an item, whose staging targets (K tile t+2, V tile
     // t+1) may already be the first tiles of the next item; all others stage from the current head.
     auto tile_iter = [&](auto slot_tag, auto cross_tag, auto last_tag, int t) __attribute__((always_inline)) {
@@ -927,10 +932,25 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       pipeline_step<D, true, !LAST, false>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA,
                                            sB, pB, pA, st, lsum, 0, N, lane);
       step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
+      if constexpr (LAST) {
+        // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
+        // loads have the last step, the last P V product and the output stores to land.
+        if (has_next) fetch_q(next_item);
+      }
       pipeline_step<D, !LAST, !LAST, false>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB,
                                             st, lsum, 0, N, lane);
       step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
-      staged_barrier();
+      if constexpr (LAST) {
+        // wait for this wave's staging pieces, which are older than the Q loads, but not for those
+        if (has_next) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQ16 * kKS) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+      } else {
+        staged_barrier();
+      }
     };
     using std::integral_constant;
     constexpr std::true_type yes{};
@@ -946,8 +966,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     tile_iter(integral_constant<int, 2>{}, yes, no, nt - 2);
     tile_iter(integral_constant<int, 3>{}, yes, yes, nt - 1);
 
-    // Q is dead: fetch the next item's (the loads land while the last P V product and the stores run)
-    if (has_next) fetch_q(next_item);
+    FLASH_STAMP(stamp_tail);
 
     // ---- P V of the last block, epilogue ------------------------------------------------------------------
     {
@@ -987,10 +1006,23 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
       }
     }
+#if defined(FLASH_PHASE_STAMPS)
+    if (!has_next) {
+      acc_pro += stamp_loop - stamp_item;
+      acc_loop += stamp_tail - stamp_loop;
+      acc_tail += __builtin_amdgcn_s_memtime() - stamp_tail;
+      FLASH_STAMP_STORE(p, wave, lane, 0ull, acc_pro, acc_pro + acc_loop, acc_pro + acc_loop + acc_tail);
+    }
+#endif
     if (!has_next) break;
     // the Q loads are older than this item's output stores: wait for everything but those stores
     wait_q<kQ16 * kDv16 / 2>(qf);
     convert_q();
+#if defined(FLASH_PHASE_STAMPS)
+    acc_pro += stamp_loop - stamp_item;
+    acc_loop += stamp_tail - stamp_loop;
+    acc_tail += __builtin_amdgcn_s_memtime() - stamp_tail;
+#endif
     item = next_item;
     k_srd = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
     v_srd = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);

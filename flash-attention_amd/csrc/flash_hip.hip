@@ -99,7 +99,7 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
   {
     static unsigned long long* buf = nullptr;
     static size_t cap = 0;
-    const size_t n = (size_t)prm.total_wg * kWaves * 8;
+    const size_t n = (size_t)grid * kWaves * 8;
     if (n > cap) {
       (void)hipMalloc(&buf, n * 8);
       cap = n;
