@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the attention-forward hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--gather-chunks C]
 
 One "step" = one forward pass of the native kernel over one synthetic batch that is already
 resident in HBM.  The default workload is the headline configuration of BASELINE.json's metric
@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo lets several ranks rehearse the "
                          "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--gather-chunks", type=int, default=0,
+                    help="also time the forward with the optional all-gather of O overlapped in this many "
+                         "head chunks (reported beside the metric, never part of `value`)")
     args = ap.parse_args()
 
     import torch
@@ -118,8 +121,11 @@ def main():
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({n_dev} visible)")
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.gather_chunks > 0:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -156,6 +162,30 @@ def main():
         t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    gather = None
+    if args.gather_chunks > 0:
+        if args.backend != "nccl":
+            raise SystemExit("--gather-chunks needs the nccl backend (device tensors)")
+        # every rank's batch is one slab of the flattened batch*heads axis of a world-times larger job
+        qs, ks, vs = (x.view(B * H, N, d) for x in (q, k, v))
+        full = torch.empty((world * B * H, N, d), dtype=q.dtype, device=dev)
+        for _ in range(max(2, args.warmup)):
+            fa.forward_shard_gather(qs, ks, vs, world * B * H, kt, chunks=args.gather_chunks, out=full, sync=False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fa.forward_shard_gather(qs, ks, vs, world * B * H, kt, chunks=args.gather_chunks, out=full, sync=False)
+        barrier()
+        tg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(full[rank * B * H:(rank + 1) * B * H], o.view(B * H, N, d)))
+        gather = {
+            "chunks": args.gather_chunks,
+            "ms_per_step": round(float(tg.item()) / args.steps * 1e3, 4),
+            "gathered_bytes_per_gpu": (world - 1) * B * H * N * d * 2,
+            "own_slab_identical_to_plain_forward": same,
+        }
 
     if rank == 0:
         flops = attention_flops(*shape)
@@ -208,9 +238,12 @@ def main():
             line["parity"] = {"max_abs_vs_cpu_oracle": err, "bar": 2e-3, "ok": bool(err <= 2e-3)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(orc, shape)
+        if gather is not None:
+            gather["exposed_ms_per_step"] = round(gather["ms_per_step"] - line["ms_per_step"], 4)
+            line["forward_plus_overlapped_gather"] = gather
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

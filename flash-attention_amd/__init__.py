@@ -223,8 +223,78 @@ def gather_output(O_local, total_heads: int, group=None):
     return torch.cat(bufs, dim=0)[:total_heads]
 
 
+def head_chunks(per_rank: int, chunks: int):
+    """Split a slab of ``per_rank`` heads into at most ``chunks`` consecutive ranges of
+    ceil(per_rank/chunks) heads (the last one may be shorter).  Returns [(c0, c1), ...]."""
+    if per_rank <= 0:
+        return []
+    chunks = max(1, min(int(chunks), per_rank))
+    step = -(-per_rank // chunks)
+    return [(c0, min(c0 + step, per_rank)) for c0 in range(0, per_rank, step)]
+
+
+def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mma_qreg_async, *,
+                         chunks: int = 4, group=None, sync: bool = True, out=None, compute=None):
+    """Forward of this rank's slab with the output all-gather overlapped with the attention kernels.
+
+    The slab is cut into ``chunks`` ranges of heads.  Each range is computed straight into its final
+    place in the replicated ``[total_heads, N, d]`` output; as soon as the kernel of one range has
+    been queued, the all-gather of that range is started (``async_op=True``: with the nccl backend
+    RCCL runs it on its own stream behind the kernel, over xGMI) while the compute stream goes on with
+    the next range.  Only the gather of the last range is exposed.  Every rank returns the full O.
+
+    Heads are independent (reference flash/kernel_mma_qreg.cuh:30-34), so any cut of the slab is
+    valid; there is no collective inside the attention itself.  The slab layout is the one of
+    :func:`shard_heads`: rank r owns flattened heads [r*per, r*per + heads_local), per =
+    ceil(total_heads / world); ranks may own fewer heads than ``per`` (or none).
+
+    ``out`` may hold a preallocated ``[world * per, N, d]`` buffer (reused from step to step).
+    ``compute(q, k, v, out)`` replaces the kernel call; it exists for hosts without a GPU (CPU tests
+    of the chunking and the collective).  The default is the HIP kernel and raises without one.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = -(-total_heads // world)
+    start, stop = shard_heads(total_heads, world, rank)
+    hl, N, d = Qs.shape
+    if hl != stop - start:
+        raise ValueError(f"rank {rank} owns {stop - start} heads, got a slab of {hl}")
+    if compute is None:
+        def compute(q, k, v, out):
+            n = q.shape[0]
+            forward(q.view(1, n, N, d), k.view(1, n, N, d), v.view(1, n, N, d), kernel_type,
+                    out=out.view(1, n, N, d), sync=False)
+
+    if out is None:
+        full = torch.empty((world * per, N, d), dtype=Qs.dtype, device=Qs.device)
+    else:
+        full = out
+        if tuple(full.shape) != (world * per, N, d) or full.dtype != Qs.dtype or full.device != Qs.device \
+                or not full.is_contiguous():
+            raise ValueError(f"out must be a contiguous [{world * per}, {N}, {d}] tensor like the slab")
+    works = []
+    for c0, c1 in head_chunks(per, chunks):
+        mine = full[rank * per + c0: rank * per + c1]
+        n_own = max(0, min(c1, hl) - c0)
+        if n_own:
+            compute(Qs[c0:c0 + n_own], Ks[c0:c0 + n_own], Vs[c0:c0 + n_own], mine[:n_own])
+        if n_own < c1 - c0:
+            mine[n_own:].zero_()  # padding rows of a short slab
+        views = [full[g * per + c0: g * per + c1] for g in range(world)]
+        works.append(dist.all_gather(views, mine, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    if sync and full.is_cuda:
+        torch.cuda.current_stream(full.device).synchronize()
+    return full[:total_heads]
+
+
 __all__ = [
     "KernelType", "LaunchInfo", "ABI_SYMBOLS", "lib", "to_string", "launch_info", "forward",
-    "load_pyflash", "shard_heads", "forward_shard", "gather_output",
+    "load_pyflash", "shard_heads", "forward_shard", "gather_output", "head_chunks",
+    "forward_shard_gather",
     "LIB_PATH", "PYFLASH_PATH", "RUNNER_PATH", "REPO_ROOT",
 ]

@@ -85,6 +85,16 @@ def test_null_pointer_and_errors_through_raw_abi(fa):
     assert rc == -2
 
 
+def test_head_chunks_cover_the_slab(fa):
+    for per in (1, 2, 3, 48, 768):
+        for chunks in (1, 2, 4, 5, 1000):
+            cs = fa.head_chunks(per, chunks)
+            assert [h for a, b in cs for h in range(a, b)] == list(range(per))
+            assert len(cs) <= min(chunks, per)
+    assert fa.head_chunks(0, 4) == []
+    assert fa.head_chunks(768, 4) == [(0, 192), (192, 384), (384, 576), (576, 768)]
+
+
 def test_shard_heads_partitions_exactly(fa):
     for total in (1, 7, 384, 6144, 13):
         for world in (1, 2, 3, 4, 8):
@@ -124,6 +134,20 @@ o_full = fa.gather_output(o_local, B * H)
 want = torch.from_numpy(orc.attn_naive(q[None], k[None], v[None])[0])
 assert o_full.shape == want.shape
 assert torch.allclose(o_full, want, atol=1e-6), (o_full - want).abs().max()
+# chunked gather overlapped with the per-chunk compute (same CPU stand-in for the kernel), for chunk
+# counts that do and do not divide the slab, including more chunks than heads
+def cpu_kernel(qc, kc, vc, out):
+    out.copy_(torch.from_numpy(orc.attn_naive(qc.numpy()[None], kc.numpy()[None], vc.numpy()[None])[0]))
+tq, tk, tv = (torch.from_numpy(x[a:b]) for x in (q, k, v))
+for chunks in (1, 2, 3, 8):
+    got = fa.forward_shard_gather(tq, tk, tv, B * H, chunks=chunks, compute=cpu_kernel)
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, atol=1e-6), (chunks, (got - want).abs().max())
+try:
+    fa.forward_shard_gather(tq[:1], tk[:1], tv[:1], B * H, compute=cpu_kernel)
+    raise SystemExit("a slab of the wrong size was accepted")
+except ValueError:
+    pass
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
