@@ -66,7 +66,8 @@ class LaunchInfo:
 
 # every symbol include/flash_hip.h declares
 ABI_SYMBOLS = (
-    "flash_fwd_f16", "flash_fwd_f32", "flash_fwd_query", "flash_kernel_type_name",
+    "flash_fwd_f16", "flash_fwd_f32", "flash_fwd_f32_ws", "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
+    "flash_kernel_type_name",
     "flash_hip_last_error", "flash_hip_version",
 )
 
@@ -92,6 +93,10 @@ def lib() -> ctypes.CDLL:
         fn = getattr(L, name)
         fn.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_int, vp]
         fn.restype = ctypes.c_int
+    L.flash_fwd_f32_ws.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_int, vp, i64, vp]
+    L.flash_fwd_f32_ws.restype = ctypes.c_int
+    L.flash_fwd_f32_workspace_bytes.argtypes = [i64, i64, i64, i64, ctypes.c_int]
+    L.flash_fwd_f32_workspace_bytes.restype = i64
     L.flash_fwd_query.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.POINTER(_LaunchInfo)]
     L.flash_fwd_query.restype = ctypes.c_int
     L.flash_kernel_type_name.argtypes = [ctypes.c_int]
@@ -136,7 +141,8 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
     """Counterpart of ``flash::forward(Q, K, V, kernel_type)`` (flash/launch.hpp:23-24).
 
     Q, K, V: 4-D ``[B, H, N, d]`` tensors on a HIP device, fp16 (native) or fp32 (the reference's
-    dtype; rounded to fp16 inside the kernel, result returned as fp32).  Returns a new tensor O of
+    dtype; rounded to fp16 by one conversion pass into per-call scratch, or inside the kernel when
+    d is not a multiple of 8; result returned as fp32).  Returns a new tensor O of
     the shape and dtype of Q.  Like the reference (flash/launch.cu:320-321) the call blocks until
     the kernel has finished unless ``sync=False``.
     """
@@ -156,11 +162,22 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
         out = torch.empty_like(Q)  # write-only for this kernel; the reference needs zeros (launch.cu:195)
     elif out.shape != Q.shape or out.dtype != Q.dtype or not out.is_contiguous() or out.device != Q.device:
         raise ValueError("out must be a contiguous tensor like Q")
-    fn = lib().flash_fwd_f16 if Q.dtype == torch.float16 else lib().flash_fwd_f32
+    scale = 1.0 / float(d) ** 0.5
     with torch.cuda.device(Q.device):
         stream = torch.cuda.current_stream(Q.device)
-        rc = fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d,
-                1.0 / float(d) ** 0.5, int(kernel_type), ctypes.c_void_p(stream.cuda_stream))
+        sp = ctypes.c_void_p(stream.cuda_stream)
+        if Q.dtype == torch.float16:
+            rc = lib().flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d,
+                                     scale, int(kernel_type), sp)
+        else:
+            # scratch for the fp16 copies of Q, K, V (the reference allocates per-call scratch too,
+            # flash/launch.cu:150-157); torch's allocator re-issues the block in stream order
+            # (a rejected shape reports -1 here; the call below then returns the matching status)
+            ws_bytes = max(0, lib().flash_fwd_f32_workspace_bytes(B, H, N, d, int(kernel_type)))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Q.device) if ws_bytes else None
+            rc = lib().flash_fwd_f32_ws(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d,
+                                        scale, int(kernel_type), ws.data_ptr() if ws is not None else None,
+                                        ws_bytes, sp)
         if rc != _OK:
             _raise(rc)
         if sync:

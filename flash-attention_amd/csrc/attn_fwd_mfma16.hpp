@@ -401,7 +401,63 @@ __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16]
   }
 }
 
-template <int D>
+// ---- epilogue of one 16-query block: O = O^T / l, written as fp16 or as fp32 ----------------------------
+// Tile b of the block holds dv = 16b + 4g + 0..3 of the lane's query.
+//  * fp16 output: two neighbouring tiles are exchanged between 16-lane rows (v_permlane16_swap) so
+//    that a lane owns 8 consecutive columns of one of them and writes one 128-bit store.
+//  * fp32 output (callers whose tensors are fp32): the four accumulators of a tile are 16 consecutive
+//    bytes of the output row already, one 128-bit store per tile.
+// Rows beyond N and columns beyond d fall outside the descriptor range and are dropped.
+template <typename TO>
+struct OutStores;
+template <>
+struct OutStores<f16> {
+  static constexpr int per_block(int dv16) { return dv16 / 2; }
+};
+template <>
+struct OutStores<float> {
+  static constexpr int per_block(int dv16) { return dv16; }
+};
+
+template <int NB, typename TO>
+__device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, uint32_t qrow, int d, int g,
+                                              __amdgpu_buffer_rsrc_t o_rs) {
+  if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+    for (int b = 0; b < NB; b += 2) {
+      f16x4 x, y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = (f16)(oq[b][j] * inv);
+        y[j] = (f16)(oq[b + 1][j] * inv);
+      }
+      const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+      u32x4 out;
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        // odd rows of the first operand trade places with even rows of the second
+        auto r = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
+        out[w] = r[0];      // g even: own tile b, cols 4g..      g odd: tile b+1 of row g-1
+        out[2 + w] = r[1];  // g even: tile b of row g+1          g odd: own tile b+1
+      }
+      const int dv = 16 * (b + (g & 1)) + 8 * (g >> 1);
+      const uint32_t off = (dv < d) ? (qrow * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      f32x4 x;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = oq[b][j] * inv;
+      const int dv = 16 * b + 4 * g;
+      const uint32_t off = (dv < d) ? (qrow * (uint32_t)d + (uint32_t)dv) * 4u : kOob;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), o_rs, off, 0, 0);
+    }
+  }
+}
+
+template <int D, typename TO = f16>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = Cfg<D>;
@@ -430,9 +486,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   const f16* qh = (const f16*)p.q + (size_t)head * head_elems;
   const f16* kh = (const f16*)p.k + (size_t)head * head_elems;
   const f16* vh = (const f16*)p.v + (size_t)head * head_elems;
-  f16* oh = (f16*)p.o + (size_t)head * head_elems;
+  TO* oh = (TO*)p.o + (size_t)head * head_elems;
   const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qh, 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, (uint32_t)(head_elems * sizeof(TO)), 0x00020000);
   const srd_t k_srd = make_srd(kh, head_bytes);
   const srd_t v_srd = make_srd(vh, head_bytes);
 
@@ -629,33 +686,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     drain_lsum(lsum);
   }
 
-  // ---- epilogue: O = O^T / l.  Tile b of query block q holds dv = 16b + 4g + 0..3 of the lane's query.
-  // Two neighbouring tiles are exchanged between 16-lane rows (v_permlane16_swap) so that a lane owns 8
-  // consecutive columns of one of them and writes one 128-bit store.
+  // ---- epilogue: O = O^T / l ---------------------------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {
     const float inv = 1.0f / quad_lane_sum(lsum[q][0], lane);
-#pragma unroll
-    for (int b = 0; b < kDv16; b += 2) {
-      f16x4 x, y;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = (f16)(o[q][b][j] * inv);
-        y[j] = (f16)(o[q][b + 1][j] * inv);
-      }
-      const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
-      u32x4 out;
-#pragma unroll
-      for (int w = 0; w < 2; ++w) {
-        // odd rows of the first operand trade places with even rows of the second
-        auto r = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
-        out[w] = r[0];      // g even: own tile b, cols 4g..      g odd: tile b+1 of row g-1
-        out[2 + w] = r[1];  // g even: tile b of row g+1          g odd: own tile b+1
-      }
-      const int dv = 16 * (b + (g & 1)) + 8 * (g >> 1);
-      const uint32_t off = (dv < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
-      __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
-    }
+    store_o_block<kDv16, TO>(o[q], inv, (uint32_t)qrow[q], d, g, o_rs);
   }
   FLASH_STAMP(stamp_end);
   FLASH_STAMP_STORE(p, wave, lane, stamp_start, stamp_loop, stamp_tail, stamp_end);
@@ -702,7 +737,7 @@ __device__ __forceinline__ void wait_q(f16x8 (&qf)[kQ16][KS]) {
   }
 }
 
-template <int D>
+template <int D, typename TO = f16>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = CfgP<D>;
@@ -834,8 +869,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const bool has_next = next_item < hi;
     const uint32_t next_head = has_next ? head_of(next_item) : head_of(item);
     const uint32_t head = head_of(item), qt = item - head * (uint32_t)p.nqt;
-    f16* oh = (f16*)p.o + (size_t)head * head_elems;
-    const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, head_bytes, 0x00020000);
+    TO* oh = (TO*)p.o + (size_t)head * head_elems;
+    const __amdgpu_buffer_rsrc_t o_rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, (uint32_t)(head_elems * sizeof(TO)), 0x00020000);
 
     // ---- item prologue: O = 0, P(-1) = 0, S(0) and its row max ------------------------------------------
 #pragma unroll
@@ -985,26 +1021,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     for (int q = 0; q < kQ16; ++q) {
       const float inv = 1.0f / quad_lane_sum(lsum[q][0], lane);
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
-#pragma unroll
-      for (int b = 0; b < kDv16; b += 2) {
-        f16x4 x, y;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          x[j] = (f16)(o[q][b][j] * inv);
-          y[j] = (f16)(o[q][b + 1][j] * inv);
-        }
-        const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
-        u32x4 out;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          auto r = __builtin_amdgcn_permlane16_swap(xu[w], yu[w], false, false);
-          out[w] = r[0];
-          out[2 + w] = r[1];
-        }
-        const int dv = 16 * (b + (g & 1)) + 8 * (g >> 1);
-        const uint32_t off = (dv < d) ? (qrow * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
-        __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
-      }
+      store_o_block<kDv16, TO>(o[q], inv, qrow, d, g, o_rs);
     }
 #if defined(FLASH_PHASE_STAMPS)
     if (!has_next) {
@@ -1016,7 +1033,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 #endif
     if (!has_next) break;
     // the Q loads are older than this item's output stores: wait for everything but those stores
-    wait_q<kQ16 * kDv16 / 2>(qf);
+    wait_q<kQ16 * OutStores<TO>::per_block(kDv16)>(qf);
     convert_q();
 #if defined(FLASH_PHASE_STAMPS)
     acc_pro += stamp_loop - stamp_item;

@@ -15,6 +15,7 @@
 
 #include "attn_fwd_mfma.hpp"
 #include "attn_fwd_mfma16.hpp"
+#include "cast_f16.hpp"
 #if defined(FLASH_PHASE_STAMPS)
 #include <cstdio>
 #include <vector>
@@ -136,11 +137,11 @@ int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
   return launch_kernel(attn_fwd_kernel<D, T, FAST>, prm, lds, stream, attr_done);
 }
 
-// fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel
-template <int D>
+// fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel; TO = element type of O
+template <int D, typename TO>
 int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
   static thread_local bool attr_done[16] = {};
-  return launch_kernel(m16::attn_fwd_kernel_m16<D>, prm, lds, stream, attr_done);
+  return launch_kernel(m16::attn_fwd_kernel_m16<D, TO>, prm, lds, stream, attr_done);
 }
 
 // FLASH_HIP_PERSISTENT=0 in the environment routes whole-tile shapes to the one-item-per-workgroup
@@ -172,12 +173,27 @@ static uint32_t persistent_grid(uint32_t items) {
 }
 
 // whole query tiles (N % 256 == 0): persistent workgroups with uninterrupted K/V staging
-template <int D>
+template <int D, typename TO>
 int launch_m16p(const FwdParams& prm, hipStream_t stream) {
   static thread_local bool attr_done[16] = {};
-  return launch_kernel(m16::attn_fwd_kernel_m16p<D>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream, attr_done,
+  return launch_kernel(m16::attn_fwd_kernel_m16p<D, TO>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream, attr_done,
                        persistent_grid(prm.total_wg));
 }
+
+// fp16 Q, K, V with 16-byte row chunks, O as fp16 or fp32
+template <typename TO>
+int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t stream) {
+  static_assert(m16::Cfg<128>::kLdsBytes == Geom<128>::kLdsBytes && m16::Cfg<64>::kLdsBytes == Geom<64>::kLdsBytes,
+                "both kernel families use the same LDS rings");
+  // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
+  // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
+  if (N % kBr == 0 && N <= persistent_max_n() && use_persistent())
+    return plan.tile_d == 64 ? launch_m16p<64, TO>(prm, stream) : launch_m16p<128, TO>(prm, stream);
+  return plan.tile_d == 64 ? launch_m16<64, TO>(prm, plan.lds, stream) : launch_m16<128, TO>(prm, plan.lds, stream);
+}
+
+// Bytes of one fp16 copy of a tensor in the workspace of flash_fwd_f32_ws (256-byte granules)
+int64_t ws_tensor_bytes(int64_t B, int64_t H, int64_t N, int64_t d) { return (B * H * N * d * 2 + 255) / 256 * 256; }
 
 template <typename T>
 int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
@@ -202,13 +218,7 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
 #if defined(FLASH_MFMA32)  // comparison builds: the 32x32x16 kernel on the fast path as well
       return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
 #else
-      static_assert(m16::Cfg<128>::kLdsBytes == Geom<128>::kLdsBytes && m16::Cfg<64>::kLdsBytes == Geom<64>::kLdsBytes,
-                    "both kernel families use the same LDS rings");
-      // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
-      // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
-      if (N % kBr == 0 && N <= persistent_max_n() && use_persistent())
-        return plan.tile_d == 64 ? launch_m16p<64>(prm, stream) : launch_m16p<128>(prm, stream);
-      return plan.tile_d == 64 ? launch_m16<64>(prm, plan.lds, stream) : launch_m16<128>(prm, plan.lds, stream);
+      return launch_fast<f16>(prm, plan, N, stream);
 #endif
     }
   }
@@ -227,6 +237,52 @@ int flash_fwd_f16(const void* q, const void* k, const void* v, void* o, int64_t 
 int flash_fwd_f32(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
                   float softmax_scale, int kernel_type, void* hip_stream) {
   return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
+}
+
+int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type) {
+  Plan plan;
+  if (make_plan(B, H, N, d, kernel_type, true, &plan) != FLASH_HIP_OK) return -1;
+  return plan.fast ? kCastTensors * ws_tensor_bytes(B, H, N, d) : 0;
+}
+
+int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                     float softmax_scale, int kernel_type, void* workspace, int64_t workspace_bytes, void* hip_stream) {
+  Plan plan;
+  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
+  if (rc != FLASH_HIP_OK) return rc;
+  if (!plan.fast || !workspace)  // rows without 16-byte chunks, or no workspace: convert while staging
+    return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
+  if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
+  const int64_t each = ws_tensor_bytes(B, H, N, d);
+  if (workspace_bytes < kCastTensors * each)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace of %lld bytes is too small: %lld needed",
+                (long long)workspace_bytes, (long long)(kCastTensors * each));
+  if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  CastParams cp;
+  const void* src[kCastTensors] = {q, k, v};
+  for (int i = 0; i < kCastTensors; ++i) {
+    cp.src[i] = (const float*)src[i];
+    cp.dst[i] = (f16*)((char*)workspace + (int64_t)i * each);
+  }
+  cp.n4 = (uint64_t)(B * H * N * d / 4);
+  // enough workgroups to keep every CU's memory pipeline full, a few trips each at large sizes
+  const uint64_t trips = (cp.n4 + kCastThreads * 4 - 1) / (kCastThreads * 4);
+  const uint32_t gx = (uint32_t)(trips < 8192 ? (trips ? trips : 1) : 8192);
+  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, cp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
+  FwdParams prm;
+  prm.q = cp.dst[0];
+  prm.k = cp.dst[1];
+  prm.v = cp.dst[2];
+  prm.o = o;
+  prm.N = (int)N;
+  prm.d = (int)d;
+  prm.nqt = (int)plan.nqt;
+  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
+  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  return launch_fast<float>(prm, plan, N, stream);
 }
 
 int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, flash_launch_info* out) {

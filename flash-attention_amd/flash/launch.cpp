@@ -1,7 +1,7 @@
 // flash::forward on MI355X: tensor checks, output allocation, one call into the C ABI
 // (include/flash_hip.h), stream synchronisation.  Replaces the body of the reference's
 // flash::forward (reference flash/launch.cu:185-324); the template dispatch and launchKernel of the
-// reference (:130-183, :216-318) live behind flash_fwd_f16 / flash_fwd_f32.
+// reference (:130-183, :216-318) live behind flash_fwd_f16 / flash_fwd_f32_ws.
 #include "launch.hpp"
 
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
@@ -52,11 +52,21 @@ torch::Tensor run(torch::Tensor Q, torch::Tensor K, torch::Tensor V, KernelType 
   auto O = torch::empty_like(Q);  // every element is written by the kernel
   const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(Q.device().index());
   const int kt = static_cast<int>(kernel_type);
-  const int rc = Q.scalar_type() == at::kHalf
-                     ? flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale,
-                                     kt, stream.stream())
-                     : flash_fwd_f32(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale,
-                                     kt, stream.stream());
+  int rc;
+  if (Q.scalar_type() == at::kHalf) {
+    rc = flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale, kt,
+                       stream.stream());
+  } else {
+    // fp32 tensors, the reference's own dtype (flash/launch.cu:165-176): per-call scratch for the fp16
+    // copies of Q, K, V, as the reference allocates l and m per call (launch.cu:150-157).  The block
+    // goes back to the caching allocator when this function returns; the allocator hands it out again
+    // in stream order, so the kernels still running on this stream keep exclusive use of it.
+    const int64_t ws_bytes = flash_fwd_f32_workspace_bytes(B, H, N, d, kt);
+    torch::Tensor workspace;
+    if (ws_bytes > 0) workspace = torch::empty({ws_bytes}, Q.options().dtype(at::kByte));
+    rc = flash_fwd_f32_ws(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale, kt,
+                          ws_bytes > 0 ? workspace.data_ptr() : nullptr, ws_bytes > 0 ? ws_bytes : 0, stream.stream());
+  }
   if (rc == FLASH_HIP_ERR_INVALID_ARGUMENT || rc == FLASH_HIP_ERR_UNSUPPORTED_DIM)
     throw std::invalid_argument(flash_hip_last_error());
   if (rc != FLASH_HIP_OK) throw std::runtime_error(flash_hip_last_error());

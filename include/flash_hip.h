@@ -95,6 +95,30 @@ int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
                   float softmax_scale, int kernel_type, void* hip_stream);
 
 /*
+ * fp32 attention forward with a caller-provided workspace: the fast path for the same fp32 callers
+ * (reference main.cpp:30-32, benchmarks/bench.py:34-36, flash/launch.cu:165-176; the reference
+ * itself allocates per-call scratch for its non-register kernels, launch.cu:150-157).
+ * When d % 8 == 0 one streaming pass rounds Q, K and V to fp16 (round-to-nearest-even, the rounding
+ * flash_fwd_f32 applies) into `workspace`, and the fp16 kernels of flash_fwd_f16 run on that copy,
+ * writing O as fp32 straight from the accumulators.  Same results as flash_fwd_f32 up to the order of
+ * fp32 additions; about three times its throughput at long sequences, because every K/V element is
+ * converted once instead of once per workgroup that reads it.
+ * `workspace`: device memory, 16-byte aligned, at least flash_fwd_f32_workspace_bytes(...) bytes;
+ * its contents are scratch and must not be touched until the work enqueued by this call has finished.
+ * A NULL workspace, or a shape for which flash_fwd_f32_workspace_bytes returns 0, makes the call
+ * behave exactly like flash_fwd_f32.  A non-NULL workspace that is too small -> INVALID_ARGUMENT.
+ */
+int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
+                     int64_t B, int64_t H, int64_t N, int64_t d,
+                     float softmax_scale, int kernel_type,
+                     void* workspace, int64_t workspace_bytes, void* hip_stream);
+
+/* Workspace flash_fwd_f32_ws uses for this shape: 3 fp16 copies of B*H*N*d elements when d % 8 == 0,
+ * 0 when the shape has no fast path, -1 (and an error text) when the shape or kernel type is
+ * rejected.  Does not touch the GPU. */
+int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type);
+
+/*
  * Geometry query; does not touch the GPU.  Replaces KernelParametersFactory::create
  * (flash/KernelParameters.hpp:383-422) for the native kernel.  Same error codes as flash_fwd_f16.
  */

@@ -72,7 +72,9 @@ static Cmp compare(const float* res, const float* ref, size_t n) {
 // spike > 0: some keys are made parallel to some query rows with a large gain, so that the running
 // max of those rows jumps by far more than any deferral threshold at chosen tiles (forces the
 // online-softmax rescale, which bounded random data never triggers)
-static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool fp32_io, int spike = 0) {
+// io: 0 = fp16 tensors, 1 = fp32 tensors (flash_fwd_f32), 2 = fp32 tensors with a workspace (flash_fwd_f32_ws)
+static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, int io, int spike = 0) {
+  const bool fp32_io = io != 0;
   const size_t n = (size_t)(B * H * N * d);
   std::vector<float> q(n), k(n), v(n), qr(n), kr(n), vr(n), ref(n), out(n);
   fill_normal(q);
@@ -118,8 +120,28 @@ static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool f
     HIP_CHECK(hipMemcpy(dv, vh.data(), n * 2, hipMemcpyHostToDevice));
   }
   HIP_CHECK(hipMemset(dout, 0xff, n * esz));  // NaN pattern: unwritten outputs show up
-  int rc = fp32_io ? flash_fwd_f32(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr)
-                   : flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
+  void* ws = nullptr;
+  int64_t ws_bytes = 0;
+  if (io == 2) {
+    ws_bytes = flash_fwd_f32_workspace_bytes(B, H, N, d, kt);
+    if (ws_bytes < 0) {
+      printf("  workspace query failed: %s\n", flash_hip_last_error());
+      return false;
+    }
+    if (ws_bytes > 0) {
+      HIP_CHECK(hipMalloc(&ws, (size_t)ws_bytes));
+      HIP_CHECK(hipMemset(ws, 0xff, (size_t)ws_bytes));
+      // a workspace that is one byte short must be refused, and nothing may have been launched
+      if (flash_fwd_f32_ws(dq, dk, dv, dout, B, H, N, d, scale, kt, ws, ws_bytes - 1, nullptr) !=
+          FLASH_HIP_ERR_INVALID_ARGUMENT) {
+        printf("  a short workspace was accepted\n");
+        return false;
+      }
+    }
+  }
+  int rc = io == 2   ? flash_fwd_f32_ws(dq, dk, dv, dout, B, H, N, d, scale, kt, ws, ws_bytes, nullptr)
+           : io == 1 ? flash_fwd_f32(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr)
+                     : flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
   bool ok = true;
   if (rc != FLASH_HIP_OK) {
     printf("  launch failed rc=%d: %s\n", rc, flash_hip_last_error());
@@ -135,7 +157,7 @@ static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool f
     Cmp c = compare(out.data(), ref.data(), n);
     ok = c.bad == 0 && c.max_abs <= 2e-3;
     printf("  (%lld,%lld,%lld,%lld) %-18s %s  max_abs=%.3e max_rel=%.3e bad=%zu nan=%zu  %s\n", (long long)B,
-           (long long)H, (long long)N, (long long)d, flash_kernel_type_name(kt), fp32_io ? "f32" : "f16", c.max_abs,
+           (long long)H, (long long)N, (long long)d, flash_kernel_type_name(kt), io == 2 ? (ws ? "f32+ws" : "f32+ws(0)") : io == 1 ? "f32" : "f16", c.max_abs,
            c.max_rel, c.bad, c.nan, ok ? "PASS" : "FAIL");
     if (!ok) {
       int shown = 0;
@@ -153,7 +175,53 @@ static bool run_shape(int64_t B, int64_t H, int64_t N, int64_t d, int kt, bool f
   HIP_CHECK(hipFree(dk));
   HIP_CHECK(hipFree(dv));
   HIP_CHECK(hipFree(dout));
+  if (ws) HIP_CHECK(hipFree(ws));
   return ok;
+}
+
+// fp32 callers: the in-kernel conversion path against the workspace path, timed back to back
+static int bench_f32(int64_t B, int64_t H, int64_t N, int64_t d, int reps) {
+  const size_t n = (size_t)(B * H * N * d);
+  std::vector<float> x(n);
+  void *dq, *dk, *dv, *dout, *ws = nullptr;
+  HIP_CHECK(hipMalloc(&dq, n * 4));
+  HIP_CHECK(hipMalloc(&dk, n * 4));
+  HIP_CHECK(hipMalloc(&dv, n * 4));
+  HIP_CHECK(hipMalloc(&dout, n * 4));
+  for (void* p : {dq, dk, dv}) {
+    fill_normal(x);
+    HIP_CHECK(hipMemcpy(p, x.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  const int kt = FLASH_KT_MMA_QREG_ASYNC;
+  const int64_t ws_bytes = flash_fwd_f32_workspace_bytes(B, H, N, d, kt);
+  if (ws_bytes > 0) HIP_CHECK(hipMalloc(&ws, (size_t)ws_bytes));
+  const float scale = 1.0f / std::sqrt((float)d);
+  hipEvent_t e0, e1;
+  HIP_CHECK(hipEventCreate(&e0));
+  HIP_CHECK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 2; ++mode) {
+    auto call = [&]() {
+      return mode ? flash_fwd_f32_ws(dq, dk, dv, dout, B, H, N, d, scale, kt, ws, ws_bytes, nullptr)
+                  : flash_fwd_f32(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
+    };
+    for (int i = 0; i < 3; ++i) {
+      if (call() != FLASH_HIP_OK) {
+        printf("launch failed: %s\n", flash_hip_last_error());
+        return 1;
+      }
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) call();
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= (float)reps;
+    printf("fp32 tensors (%lld,%lld,%lld,%lld) %-22s %.4f ms  %.1f TFLOP/s\n", (long long)B, (long long)H, (long long)N,
+           (long long)d, mode ? "flash_fwd_f32_ws" : "flash_fwd_f32", ms, 4.0 * B * H * N * N * d / (ms * 1e-3) / 1e12);
+  }
+  return 0;
 }
 
 static int bench_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps, int kt) {
@@ -280,6 +348,9 @@ int main(int argc, char** argv) {
   if (argc >= 6 && std::string(argv[1]) == "ab") {
     return ab_shape(atoll(argv[2]), atoll(argv[3]), atoll(argv[4]), atoll(argv[5]), argc > 6 ? atoi(argv[6]) : 30);
   }
+  if (argc >= 6 && std::string(argv[1]) == "benchf32") {
+    return bench_f32(atoll(argv[2]), atoll(argv[3]), atoll(argv[4]), atoll(argv[5]), argc > 6 ? atoi(argv[6]) : 20);
+  }
   if (argc >= 6 && std::string(argv[1]) == "bench") {
     const int reps = argc > 6 ? atoi(argv[6]) : 20;
     const int kt = argc > 7 ? atoi(argv[7]) : FLASH_KT_MMA_QREG_ASYNC;
@@ -302,15 +373,17 @@ int main(int argc, char** argv) {
     for (int kt : kts) {
       if (kt == FLASH_KT_MMA_QREG && s.d % 2) continue;  // reference guards, main.cpp:114-126
       if ((kt == FLASH_KT_MMA_QREG_F32X4LOAD || kt == FLASH_KT_MMA_QREG_ASYNC) && s.d % 4) continue;
-      all &= run_shape(s.B, s.H, s.N, s.d, kt, false);
+      all &= run_shape(s.B, s.H, s.N, s.d, kt, 0);
     }
-    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, true);
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, 1);
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, 2);
   }
   printf("forced rescale (spiked keys)\n");
   const Shape spiked[] = {{1, 2, 640, 128}, {2, 2, 1000, 64}, {1, 1, 2048, 128}, {1, 2, 333, 72}};
   for (const Shape& s : spiked) {
-    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_MMA_QREG_ASYNC, false, 6);
-    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, true, 6);
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_MMA_QREG_ASYNC, 0, 6);
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, 1, 6);
+    all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, 2, 6);
   }
   printf(all ? "ALL PASS\n" : "SOME FAILED\n");
   return all ? 0 : 1;

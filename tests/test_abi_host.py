@@ -85,6 +85,20 @@ def test_null_pointer_and_errors_through_raw_abi(fa):
     assert rc == -2
 
 
+def test_fp32_workspace_size_query(fa):
+    """No GPU needed: three fp16 copies (256-byte granules) when rows have 16-byte chunks, else 0;
+    -1 with the reference's error text for shapes flash::forward rejects."""
+    L = fa.lib()
+    assert L.flash_fwd_f32_workspace_bytes(4, 96, 4096, 128, 11) == 3 * 4 * 96 * 4096 * 128 * 2
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 3, 8, 0) == 3 * 256
+    assert L.flash_fwd_f32_workspace_bytes(5, 12, 53, 69, 0) == 0
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 50, 9) == 0
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 50, 11) == -1
+    assert b"multiple of 4" in L.flash_hip_last_error()
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 256, 11) == -1
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 64, 12) == -1
+
+
 def test_head_chunks_cover_the_slab(fa):
     for per in (1, 2, 3, 48, 768):
         for chunks in (1, 2, 4, 5, 1000):

@@ -24,16 +24,27 @@ def torch_gpu():
     return torch
 
 
-def run_abi(fa, torch, q, k, v, kt, dtype):
-    """q, k, v: numpy [B, H, N, d] fp32 -> numpy fp32 O, straight through flash_fwd_f16/_f32."""
+def run_abi(fa, torch, q, k, v, kt, dtype, workspace=False):
+    """q, k, v: numpy [B, H, N, d] fp32 -> numpy fp32 O, straight through flash_fwd_f16 / _f32, or
+    through flash_fwd_f32_ws with a workspace of the size the library asks for."""
     B, H, N, d = q.shape
     tq, tk, tv = (torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0", dtype) for x in (q, k, v))
     out = torch.full_like(tq, float("nan"))
-    fn = fa.lib().flash_fwd_f16 if dtype == torch.float16 else fa.lib().flash_fwd_f32
+    L = fa.lib()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    rc = fn(tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out.data_ptr(), B, H, N, d,
-            1.0 / np.sqrt(d), int(kt), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    assert rc == 0, fa.lib().flash_hip_last_error()
+    if workspace:
+        assert dtype == torch.float32
+        nbytes = L.flash_fwd_f32_workspace_bytes(B, H, N, d, int(kt))
+        assert nbytes == (3 * ((B * H * N * d * 2 + 255) // 256 * 256) if d % 8 == 0 else 0)
+        ws = torch.full((max(nbytes, 1),), 0xFF, dtype=torch.uint8, device="cuda:0")
+        rc = L.flash_fwd_f32_ws(tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out.data_ptr(), B, H, N, d,
+                                1.0 / np.sqrt(d), int(kt), ws.data_ptr() if nbytes else None, nbytes, stream)
+    else:
+        fn = L.flash_fwd_f16 if dtype == torch.float16 else L.flash_fwd_f32
+        rc = fn(tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out.data_ptr(), B, H, N, d,
+                1.0 / np.sqrt(d), int(kt), stream)
+    assert rc == 0, L.flash_hip_last_error()
     torch.cuda.synchronize()
     return out.float().cpu().numpy()
 
@@ -60,6 +71,8 @@ def test_golden_vectors_all_kernel_types(fa, torch_gpu, shape):
     # fp32 callers: unrounded fp32 inputs, rounded to fp16 inside the kernel, fp32 output
     o = run_abi(fa, torch_gpu, g["q32"], g["k32"], g["v32"], fa.KernelType.naive1D, torch_gpu.float32)
     assert_close(o, g["o"], f"{shape} fp32 entry point")
+    o = run_abi(fa, torch_gpu, g["q32"], g["k32"], g["v32"], fa.KernelType.naive1D, torch_gpu.float32, workspace=True)
+    assert_close(o, g["o"], f"{shape} fp32 entry point with workspace")
 
 
 SEEDED = [
@@ -83,6 +96,39 @@ def test_seeded_shapes_vs_oracle(fa, oracle, torch_gpu, shape):
         assert_close(o, ref, f"{shape} fp16 async")
     o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma, torch_gpu.float32)
     assert_close(o, ref, f"{shape} fp32")
+    o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma, torch_gpu.float32, workspace=True)
+    assert_close(o, ref, f"{shape} fp32 with workspace")
+
+
+def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gpu):
+    """fp32 tensors that are NOT fp16-representable: the conversion pass into the workspace and the
+    in-kernel conversion round the same way (to nearest even), so both agree with the oracle on the
+    rounded inputs and with each other far inside the bar; a short workspace is refused; no workspace
+    means the in-kernel path."""
+    torch = torch_gpu
+    L = fa.lib()
+    for shape in ((2, 3, 512, 128), (1, 4, 333, 64), (2, 2, 1024, 72)):
+        B, H, N, d = shape
+        rng = np.random.default_rng(N)
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.37) for _ in range(3))
+        ref = oracle.attn_naive(*(oracle.round_f16(x) for x in (q, k, v)))
+        a = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32)
+        b = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32, workspace=True)
+        assert_close(a, ref, f"{shape} in-kernel conversion")
+        assert_close(b, ref, f"{shape} workspace conversion")
+        assert np.abs(a - b).max() <= 1e-3   # two kernel families: different (in-bar) roundings of Q*scale
+    tq = torch.randn(shape, device="cuda:0")
+    out = torch.empty_like(tq)
+    need = L.flash_fwd_f32_workspace_bytes(B, H, N, d, 11)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+    args = (tq.data_ptr(), tq.data_ptr(), tq.data_ptr(), out.data_ptr(), B, H, N, d, 0.1, 11)
+    assert L.flash_fwd_f32_ws(*args, ws.data_ptr(), need - 1, None) == -1
+    assert b"too small" in L.flash_hip_last_error()
+    assert L.flash_fwd_f32_ws(*args, ws.data_ptr() + 2, need, None) == -1     # misaligned
+    assert L.flash_fwd_f32_ws(*args, None, 0, None) == 0                       # no workspace: plain fp32 path
+    assert L.flash_fwd_f32_workspace_bytes(B, H, N, 129, 11) == -1             # rejected shape
+    assert L.flash_fwd_f32_workspace_bytes(B, H, N, 50, 7) == 0                # no 16-byte row chunks
+    torch.cuda.synchronize()
 
 
 def test_forced_rescale_spike(fa, oracle, torch_gpu):
