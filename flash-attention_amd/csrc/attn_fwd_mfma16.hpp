@@ -120,18 +120,24 @@ __device__ __forceinline__ void drain_s(f32x4 (&s)[2][kQ16]) {
                  "+v"(s[1][2]), "+v"(s[1][3]));
 }
 
-// max / sum over the four lanes (g = 0..3) that share a query column.  Only used on rare paths.
-__device__ __forceinline__ float quad_lane_max(float x, int lane) {
-  float y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_uint(x)));
-  x = fmaxf(x, y);
-  y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_uint(x)));
-  return fmaxf(x, y);
+// max / sum over the four lanes (g = 0..3) that share a query column, result in all four.  The 16-lane
+// rows are exchanged with v_permlane16_swap / v_permlane32_swap, which run on the vector ALU: no LDS
+// round trip.  With both operands equal to x, permlane16_swap leaves rows {0,0,2,2} of x in one
+// register and rows {1,1,3,3} in the other; permlane32_swap leaves the lower half twice / the upper
+// half twice.  Every lane combines the four values in the same order.
+__device__ __forceinline__ float quad_lane_max(float x, int) {
+  const uint32_t u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const uint32_t m = __float_as_uint(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+  const auto t = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+  return fmaxf(__uint_as_float(t[0]), __uint_as_float(t[1]));
 }
-__device__ __forceinline__ float quad_lane_sum(float x, int lane) {
-  float y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_uint(x)));
-  x += y;
-  y = __uint_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_uint(x)));
-  return x + y;
+__device__ __forceinline__ float quad_lane_sum(float x, int) {
+  const uint32_t u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const uint32_t m = __float_as_uint(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+  const auto t = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
 template <int D>
@@ -425,12 +431,9 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
   if constexpr (sizeof(TO) == 2) {
 #pragma unroll
     for (int b = 0; b < NB; b += 2) {
-      f16x4 x, y;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        x[j] = (f16)(oq[b][j] * inv);
-        y[j] = (f16)(oq[b + 1][j] * inv);
-      }
+      // packed multiplies, then packed conversions: the pairs come out in the layout the stores need
+      const f32x4 xs = oq[b] * inv, ys = oq[b + 1] * inv;
+      const f16x4 x = __builtin_convertvector(xs, f16x4), y = __builtin_convertvector(ys, f16x4);
       const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
       u32x4 out;
 #pragma unroll
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   // ---- epilogue: O = O^T / l ---------------------------------------------------------------------------
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {
-    const float inv = 1.0f / quad_lane_sum(lsum[q][0], lane);
+    const float inv = __builtin_amdgcn_rcpf(quad_lane_sum(lsum[q][0], lane));  // v_rcp_f32, 1 ulp
     store_o_block<kDv16, TO>(o[q], inv, (uint32_t)qrow[q], d, g, o_rs);
   }
   FLASH_STAMP(stamp_end);
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
-      const float inv = 1.0f / quad_lane_sum(lsum[q][0], lane);
+      const float inv = __builtin_amdgcn_rcpf(quad_lane_sum(lsum[q][0], lane));  // v_rcp_f32, 1 ulp
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
       store_o_block<kDv16, TO>(o[q], inv, qrow, d, g, o_rs);
     }
