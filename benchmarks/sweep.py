@@ -6,8 +6,9 @@ behind its img/scalability.png): B=4, H=96, d=128 (bench.py:28-31), N = 512 ... 
 implementation, times in milliseconds in a dict of the same shape
     {"Sequence Length": [...], "<kernel name>": [ms, ...], ...}
 so the reference's plot can be regenerated from it.  Differences, on purpose: inputs are fp16 (the
-native kernel's storage type), every kernel is warmed up and the median of several HIP-event timings
-is reported (the reference profiles one cold call, bench.py:58-66), and TFLOP/s = 4*B*H*N^2*d / t is
+native kernel's storage type; one extra row feeds it fp32 tensors as the reference does), every kernel
+is warmed up and the average of several back-to-back calls is reported (the reference profiles one
+cold call, bench.py:58-66), and TFLOP/s = 4*B*H*N^2*d / t is
 printed next to the times.
 
 Rows
@@ -16,6 +17,7 @@ Rows
   mma_qreg_async     torch.ops.pyflash.mma_qreg_async -> native kernel
   torch_flash_v2     torch.nn.functional.scaled_dot_product_attention in fp16 (whatever backend
                      PyTorch-ROCm selects)
+  mma_qreg_async_fp32  the same op on fp32 tensors (conversion pass into scratch + fp16 kernel, fp32 out)
 
   python benchmarks/sweep.py [--out profiles/sweep.json] [--max-n 16384] [--reps 10]
 """
@@ -26,7 +28,6 @@ import importlib
 import json
 import math
 import os
-import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -63,22 +64,24 @@ def main():
         ("mma_qreg_vld", pyflash.mma_qreg_vld),
         ("mma_qreg_async", pyflash.mma_qreg_async),
         ("torch_flash_v2", F.scaled_dot_product_attention),
+        # the reference's own tensor dtype: fp32 in, fp32 out (conversion pass + fp16 kernel)
+        ("mma_qreg_async_fp32", lambda q, k, v: pyflash.mma_qreg_async(q32, k32, v32)),
     ]
 
     def time_ms(fn, q, k, v):
+        """Average over `reps` back-to-back calls (sustained clocks; single calls separated by host
+        synchronisation run at boost clocks and read up to 15 % faster at short sequences)."""
         for _ in range(3):
             fn(q, k, v)
         torch.cuda.synchronize(dev)
-        ts = []
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(args.reps):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
             fn(q, k, v)
-            e1.record()
-            e1.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        return statistics.median(ts)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / args.reps
 
     seqs = [n for n in (512, 1024, 2048, 4096, 8192, 16384) if n <= args.max_n]
     data = {"Sequence Length": seqs}
@@ -86,6 +89,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(0)
     for N in seqs:
         q, k, v = (torch.randn(B, H, N, d, device=dev, generator=gen).half() for _ in range(3))
+        q32, k32, v32 = q.float(), k.float(), v.float()
         flops = 4.0 * B * H * N * N * d
         print(f"\nseq_len {N}", flush=True)
         ref = None
@@ -104,13 +108,13 @@ def main():
         if ref is not None:
             err = float((pyflash.mma_qreg_async(q, k, v).float() - ref.float()).abs().max())
             print(f"  max |native - torch SDPA| = {err:.2e}")
-        del q, k, v
+        del q, k, v, q32, k32, v32
         torch.cuda.empty_cache()
 
     print()
     print(data)
     result = {"shape": {"B": B, "H": H, "d": d, "dtype": "fp16"}, "ms": data, "tflops": tflops,
-              "method": f"median of {args.reps} HIP-event timings after 3 warm-up calls, one MI355X",
+              "method": f"average of {args.reps} back-to-back calls between two HIP events after 3 warm-up calls, one MI355X",
               "torch": torch.__version__}
     if args.out:
         with open(args.out, "w") as f:
