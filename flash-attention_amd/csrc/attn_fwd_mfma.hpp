@@ -238,6 +238,18 @@ __device__ __forceinline__ void dma_piece(srd_t srd, uint32_t voff, uint32_t lds
       : "memory");
 }
 
+// Same, with the LDS address given as a wave-uniform base register plus a compile-time offset: one
+// scalar register serves every piece of every ring slot.
+__device__ __forceinline__ void dma_piece_at(srd_t srd, uint32_t voff, uint32_t lds_wave_base, uint32_t lds_const) {
+  asm volatile(
+      "s_add_u32 m0, %0, %1\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %2, %3, 0 offen lds"
+      :
+      : "s"(lds_wave_base), "i"(lds_const), "v"(voff), "s"(srd)
+      : "memory", "scc");
+}
+
 // ---- element access through a raw buffer descriptor (range-checked) --------------------------
 template <typename T>
 __device__ __forceinline__ f16 load_elem(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off);

@@ -91,6 +91,16 @@ __device__ __forceinline__ void mfma_o(f32x4& acc, const f16x8& a, const f16x8& 
   }
 }
 
+// First P V product of a work item: srcC is the constant 0, so the accumulators need no clearing.
+__device__ __forceinline__ void mfma_o_first0(f32x4& acc, const f16x8& a, const f16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
+
+// What the P V slots of a pipeline step do
+constexpr int kPvAccumulate = 0;  // O += V^T P^T
+constexpr int kPvSkip = 1;        // nothing: the very first step of an item has no P yet
+constexpr int kPvFirst = 2;       // O  = V^T P^T (first product of an item)
+
 // Row sums on the matrix pipe: v_mfma_f32_4x4x4_16b_f16 computes, for 16 independent 4x4 blocks,
 // D[i][j] = sum_k A[i][k] B[k][j] + C[i][j], where a lane holds the four k-values of one column j of B
 // and gets D[0..3][j] in its four result registers.  With A = all ones every D[i][j] of a lane is the
@@ -208,7 +218,7 @@ __device__ __forceinline__ void mask_tile(f32x4& s, int kv_tile0, int N, int lan
 // One pipeline step: QK(j+1) (32 MFMAs), PV(j-1) (32 MFMAs), exp(j), in-lane max(j+1).
 //   s_cur/s_nxt[kb][q]: S^T tiles of key block kb (16 keys) and query block q (16 queries)
 //   p_prev/p_cur[q]:    P^T fragments (32 keys) of query block q
-template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, typename Hook>
+template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, int PV_MODE = kPvAccumulate, typename Hook>
 __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off, uint32_t vb_off, uint32_t kb_next_off,
                                               const LaneAddr<D>& la, const f32x4 (&bias)[kQ16],
                                               const f16x8 (&qf)[kQ16][Cfg<D>::kKS], f16x8 (&ka)[4],
@@ -318,7 +328,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
         }
       }
       // the first four V^T fragments, shortly before the PV slots begin
-      if (n >= QK_SLOTS - 10 && n < QK_SLOTS - 2 && ((n - (QK_SLOTS - 10)) & 1) == 0) {
+      if (PV_MODE != kPvSkip && n >= QK_SLOTS - 10 && n < QK_SLOTS - 2 && ((n - (QK_SLOTS - 10)) & 1) == 0) {
         const int b = (n - (QK_SLOTS - 10)) / 2;
         va[b] = read_v<D>(vb_off, la, b);
       }
@@ -333,9 +343,13 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
       const int pslot = b * kQ16 + q;
-      mfma_o<false>(o[q][b], va[b % 4], p_prev[q]);
+      if constexpr (PV_MODE == kPvFirst) {
+        mfma_o_first0(o[q][b], va[b % 4], p_prev[q]);
+      } else if constexpr (PV_MODE == kPvAccumulate) {
+        mfma_o<false>(o[q][b], va[b % 4], p_prev[q]);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if (q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
+      if (PV_MODE != kPvSkip && q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
       exp_share(QK_SLOTS + pslot);
       hook(QK_SLOTS + pslot);
       if constexpr (HAS_QK) {
@@ -785,10 +799,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const int src = (ci % C::kChunks) ^ swz<D>(row);
     dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
   }
-  auto piece = [&](const srd_t srd, lds_char* ring, int slot, int t, int i) __attribute__((always_inline)) {
-    const int pc = wave * kPiecesPerWave + i;
-    const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + slot * kTileBytes + pc * 1024));
-    dma_piece(srd, dma_off[i] + (uint32_t)t * tile_step, lds_base);
+  // LDS address of this wave's first piece in slot 0 of the K ring; the ring (K or V), the slot and the
+  // piece number add a compile-time constant
+  const uint32_t lds_wave_base =
+      __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(k_ring + wave * kPiecesPerWave * 1024));
+  auto piece = [&](const srd_t srd, bool v_side, int slot, int t, int i) __attribute__((always_inline)) {
+    dma_piece_at(srd, dma_off[i] + (uint32_t)t * tile_step, lds_wave_base,
+                 (uint32_t)(((v_side ? kRingP : 0) + slot) * kTileBytes + i * 1024));
   };
   auto staged_barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -823,13 +840,24 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
   };
   // pre-multiply by softmax_scale * log2(e); the registers come back as accumulation registers
+  // (v_fma_mix: fp16 halves in, fp32 product, one rounding back to fp16 -- two instructions per register)
   auto convert_q = [&]() __attribute__((always_inline)) {
+    const float sc = p.scale_log2e;
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
       for (int ks = 0; ks < kKS; ++ks) {
+        u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
+        for (int j = 0; j < 4; ++j) {
+          uint32_t x = w[j];
+          asm("v_fma_mixlo_f16 %0, %0, %1, 0 op_sel_hi:[1,0,0]\n\t"
+              "v_fma_mixhi_f16 %0, %0, %1, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+              : "+v"(x)
+              : "v"(sc));
+          w[j] = x;
+        }
+        qf[q][ks] = __builtin_bit_cast(f16x8, w);
         asm volatile("" : "+a"(qf[q][ks]));
       }
     }
@@ -840,16 +868,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   srd_t v_srd = make_srd((const f16*)p.v + (size_t)head_of(item) * head_elems, head_bytes);
   fetch_q(item);
 #pragma unroll
-  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, k_ring, 0, 0, i);
+  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 0, 0, i);
 #pragma unroll
-  for (int i = 0; i < kPiecesPerWave; ++i) piece(v_srd, v_ring, 0, 0, i);
+  for (int i = 0; i < kPiecesPerWave; ++i) piece(v_srd, true, 0, 0, i);
 #pragma unroll
-  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, k_ring, 1, 1, i);
-  // Step 0 of an item multiplies P(-1) = 0 with the second block of "V tile -1" (slot 3): later items
-  // find the previous item's last tile there, the first one needs something finite.
-  for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
-    *FLASH_LDS_CAST(u32x4, v_ring + 3 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
-  }
+  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 1, 1, i);
   const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
   wait_q<0>(qf);
   convert_q();
@@ -876,21 +899,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const __amdgpu_buffer_rsrc_t o_rs =
         __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, (uint32_t)(head_elems * sizeof(TO)), 0x00020000);
 
-    // ---- item prologue: O = 0, P(-1) = 0, S(0) and its row max ------------------------------------------
-#pragma unroll
-    for (int q = 0; q < kQ16; ++q) {
-#pragma unroll
-      for (int b = 0; b < kDv16; ++b) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[q][b][i] = 0.f;
-        asm volatile("" : "+a"(o[q][b]));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pB[q][j] = (f16)0.f;
-      // opaque from here on: a constant would be re-materialised right in front of the MFMA that
-      // reads it, too close for an instruction the compiler does not know to be an MFMA
-      asm volatile("" : "+v"(pB[q]));
-    }
+    // ---- item prologue: S(0) and its row max.  O is not cleared: the first P V product of the item
+    // (second step of tile 0) takes the constant 0 as its addend.
 #pragma unroll
     for (int f = 0; f < 4; ++f) ka[f] = read_k<D>(0u, la, f / kKS, f % kKS);
 #pragma unroll
@@ -935,10 +945,12 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     FLASH_STAMP(stamp_loop);
     // CROSS marks the last two tile iterations of an item, whose staging targets (K tile t+2, V tile
     // t+1) may already be the first tiles of the next item; all others stage from the current head.
-    auto tile_iter = [&](auto slot_tag, auto cross_tag, auto last_tag, int t) __attribute__((always_inline)) {
+    auto tile_iter = [&](auto slot_tag, auto cross_tag, auto last_tag, auto first_tag, int t) __attribute__((always_inline)) {
       constexpr int S0 = decltype(slot_tag)::value;
       constexpr bool CROSS = decltype(cross_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;
+      // tile 0 of an item: its first step has no P to multiply yet, its second step starts O
+      constexpr bool FIRST = decltype(first_tag)::value;
       constexpr int S1 = (S0 + 1) % 4, S2 = (S0 + 2) % 4, S3 = (S0 + 3) % 4;
       const bool k_cur_item = !CROSS || t + 2 < nt, v_cur_item = !CROSS || t + 1 < nt;
       srd_t ks_srd = k_srd, vs_srd = v_srd;
@@ -960,24 +972,24 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         if (n % kSpacing == 1) {
           const int i = n / kSpacing;
           if (i < kPiecesPerWave) {
-            if (!CROSS || k_go) piece(ks_srd, k_ring, S2, k_tile, i);
+            if (!CROSS || k_go) piece(ks_srd, false, S2, k_tile, i);
           } else if (i < 2 * kPiecesPerWave) {
-            if (!CROSS || v_go) piece(vs_srd, v_ring, S1, v_tile, i - kPiecesPerWave);
+            if (!CROSS || v_go) piece(vs_srd, true, S1, v_tile, i - kPiecesPerWave);
           }
         }
       };
       constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
       constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
-      pipeline_step<D, true, !LAST, false>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA,
-                                           sB, pB, pA, st, lsum, 0, N, lane);
+      pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate>(
+          dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, st, lsum, 0, N, lane);
       step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
       if constexpr (LAST) {
         // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
         // loads have the last step, the last P V product and the output stores to land.
         if (has_next) fetch_q(next_item);
       }
-      pipeline_step<D, !LAST, !LAST, false>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB,
-                                            st, lsum, 0, N, lane);
+      pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate>(
+          no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st, lsum, 0, N, lane);
       step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
       if constexpr (LAST) {
         // wait for this wave's staging pieces, which are older than the Q loads, but not for those
@@ -994,16 +1006,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     using std::integral_constant;
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
-    tile_iter(integral_constant<int, 0>{}, no, no, 0);
-    tile_iter(integral_constant<int, 1>{}, no, no, 1);
+    tile_iter(integral_constant<int, 0>{}, no, no, yes, 0);
+    tile_iter(integral_constant<int, 1>{}, no, no, no, 1);
     for (int t = 2; t + 2 < nt; t += 4) {
-      tile_iter(integral_constant<int, 2>{}, no, no, t);
-      tile_iter(integral_constant<int, 3>{}, no, no, t + 1);
-      tile_iter(integral_constant<int, 0>{}, no, no, t + 2);
-      tile_iter(integral_constant<int, 1>{}, no, no, t + 3);
+      tile_iter(integral_constant<int, 2>{}, no, no, no, t);
+      tile_iter(integral_constant<int, 3>{}, no, no, no, t + 1);
+      tile_iter(integral_constant<int, 0>{}, no, no, no, t + 2);
+      tile_iter(integral_constant<int, 1>{}, no, no, no, t + 3);
     }
-    tile_iter(integral_constant<int, 2>{}, yes, no, nt - 2);
-    tile_iter(integral_constant<int, 3>{}, yes, yes, nt - 1);
+    tile_iter(integral_constant<int, 2>{}, yes, no, no, nt - 2);
+    tile_iter(integral_constant<int, 3>{}, yes, yes, no, nt - 1);
 
     FLASH_STAMP(stamp_tail);
 
