@@ -220,7 +220,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
                 "traffic": measured_traffic(args.workload),
-                "kernel": f"flash_hip::m16::attn_fwd_kernel_m16p<{128 if d > 64 else 64}>" if N % 256 == 0 else f"flash_hip::m16::attn_fwd_kernel_m16<{128 if d > 64 else 64}>",
+                "kernel": f"flash_hip::m16::attn_fwd_kernel_m16{'p' if N % 256 == 0 else ''}<{128 if d > 64 else 64}, _Float16>",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops,
             },
