@@ -221,6 +221,9 @@ def main():
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
                 "traffic": measured_traffic(args.workload),
                 "kernel": f"flash_hip::m16::attn_fwd_kernel_m16{'p' if N % 256 == 0 else ''}<{128 if d > 64 else 64}, _Float16>",
+                # the same kernel as rocprofv3's CSV output names it (mangled)
+                "kernel_symbol": "_ZN9flash_hip3m16{}attn_fwd_kernel_m16{}ILi{}EDF16_EEvNS_9FwdParamsE".format(
+                    20 if N % 256 == 0 else 19, "p" if N % 256 == 0 else "", 128 if d > 64 else 64),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops,
             },
