@@ -239,14 +239,16 @@ __device__ __forceinline__ void dma_piece(srd_t srd, uint32_t voff, uint32_t lds
 }
 
 // Same, with the LDS address given as a wave-uniform base register plus a compile-time offset: one
-// scalar register serves every piece of every ring slot.
-__device__ __forceinline__ void dma_piece_at(srd_t srd, uint32_t voff, uint32_t lds_wave_base, uint32_t lds_const) {
+// scalar register serves every piece of every ring slot.  // `soff` is a wave-uniform byte offset added to the address after the range check (which sees `voff`
+// only): the caller must know that voff + soff stays inside the buffer whenever voff does.
+__device__ __forceinline__ void dma_piece_at(srd_t srd, uint32_t voff, uint32_t soff, uint32_t lds_wave_base,
+                                             uint32_t lds_const) {
   asm volatile(
       "s_add_u32 m0, %0, %1\n\t"
       "s_nop 0\n\t"
-      "buffer_load_dwordx4 %2, %3, 0 offen lds"
+      "buffer_load_dwordx4 %2, %3, %4 offen lds"
       :
-      : "s"(lds_wave_base), "i"(lds_const), "v"(voff), "s"(srd)
+      : "s"(lds_wave_base), "i"(lds_const), "v"(voff), "s"(srd), "s"(soff)
       : "memory", "scc");
 }
 

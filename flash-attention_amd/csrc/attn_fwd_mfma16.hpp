@@ -804,7 +804,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const uint32_t lds_wave_base =
       __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(k_ring + wave * kPiecesPerWave * 1024));
   auto piece = [&](const srd_t srd, bool v_side, int slot, int t, int i) __attribute__((always_inline)) {
-    dma_piece_at(srd, dma_off[i] + (uint32_t)t * tile_step, lds_wave_base,
+    // whole tiles only (N % 64 == 0): the tile offset can bypass the range check as a scalar offset
+    dma_piece_at(srd, dma_off[i], __builtin_amdgcn_readfirstlane((uint32_t)t * tile_step), lds_wave_base,
                  (uint32_t)(((v_side ? kRingP : 0) + slot) * kTileBytes + i * 1024));
   };
   auto staged_barrier = [&]() __attribute__((always_inline)) {
