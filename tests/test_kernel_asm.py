@@ -46,7 +46,7 @@ def main_loop(lines, min_mfma=90):
             continue
         lab = m.group(1)
         for j in range(i + 1, len(lines)):
-            if re.search(r"s_cbranch_\w+\s+" + re.escape(lab) + r"\b", lines[j]):
+            if re.search(r"s_(cbranch_\w+|branch)\s+" + re.escape(lab) + r"\b", lines[j]):
                 body = lines[i:j + 1]
                 if sum("v_mfma_f32_16x16x32" in x for x in body) >= min_mfma and (best is None or len(body) < len(best)):
                     best = body
