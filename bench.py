@@ -5,7 +5,7 @@
 
 One "step" = one forward pass of the native kernel over one synthetic batch that is already
 resident in HBM.  The default workload is the headline configuration of BASELINE.json's metric
-(fp16, B=4, H=96, N=4096, d=128); `--workload gpt3_1k` is configs[1] (N=1024) and `--workload
+(fp16, B=8, H=96, N=4096, d=128 per GPU: B=64 over 8 GPUs is configs[4]); `--workload gpt3_1k` is configs[1] (N=1024) and `--workload
 d64` is the small-head configuration (16, 32, 2048, 64).  With N > 1 GPUs (launched through
 torch.distributed.run, one rank per GPU) every rank owns its own batch of the same shape — the
 batch x heads axis is what shards, there is no collective on the data path — so scaling is weak and
@@ -30,7 +30,10 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # name: (B, H, N, d)
-    "headline": (4, 96, 4096, 128),   # target shape of the metric: H=96, d=128, N=4096
+    # target shape of the metric (H=96, d=128, N=4096) with the per-GPU batch of configs[4]: B=64 over 8
+    # GPUs is 8 per GPU, so the 8-GPU run of this weak-scaling benchmark is exactly that configuration
+    "headline": (8, 96, 4096, 128),
+    "gpt3_4k_b4": (4, 96, 4096, 128),  # the same head shape at the batch of configs[1] and [2]
     "gpt3_1k": (4, 96, 1024, 128),    # BASELINE.json configs[1]
     "gpt3_2k": (4, 96, 2048, 128),    # the reference runner's benchmark shape (main.cpp:197-202)
     "d64": (16, 32, 2048, 64),        # configs[3]

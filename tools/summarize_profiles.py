@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
-B, H, N, D = 4, 96, 4096, 128
+B, H, N, D = 8, 96, 4096, 128
 
 rows = list(csv.reader(open(os.path.join(SRC, "kt", "bench_kernel_stats.csv"))))
 with open(os.path.join(DST, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
@@ -40,7 +40,7 @@ m = lambda k: pmc[k]["mean_per_launch"]
 fetch, write = m("FETCH_SIZE") * 1024, m("WRITE_SIZE") * 1024
 hbm = 2 * fetch + write
 out = {
-    "command": "rocprofv3 --pmc <counters> --output-format csv -- tests/native/selftest bench 4 96 4096 128 5 11"
+    "command": "rocprofv3 --pmc <counters> --output-format csv -- tests/native/selftest bench 8 96 4096 128 5 11"
                "  (one pass per counter group, tools/gpu_profile.sh)",
     "kernel": kernel, "workload": f"({B},{H},{N},{D}) fp16", "counters": pmc,
     "derived": {
