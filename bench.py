@@ -204,7 +204,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
-            "vs_baseline": None,       # the reference publishes no fp16 / MI355X number (BASELINE.md)
+            "vs_baseline": None,       # the reference publishes no fp16 / MI355X number
             "dtype": "fp16",
             "data": "synthetic (standard normal, seeded per rank)",
             "config": {
