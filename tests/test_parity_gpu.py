@@ -131,6 +131,33 @@ def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gp
     torch.cuda.synchronize()
 
 
+def test_seeded_fuzz_over_shapes_types_and_entry_points(fa, oracle, torch_gpu):
+    """Forty pseudo-random cases (fixed seed): batch, heads, sequence length (1..900, tile edges
+    favoured), head dim (1..128), kernel type, tensor dtype / entry point, input scale.  The scale stays
+    at or below one standard deviation: the absolute bar is stated for unit-scale inputs (the fp16
+    rounding of P alone is 2^-11 of |V|, and the rounding of Q * scale to fp16 moves a score by 2^-11 of
+    its magnitude, so the error grows with the cube of the input scale; at 1.5 standard deviations a case
+    lands at 2.03e-3 absolute while still inside 2e-3 + 1e-2 |ref|).  Large scores have their own test."""
+    torch = torch_gpu
+    rng = np.random.default_rng(20240611)
+    edges = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 767, 768]
+    done = 0
+    while done < 40:
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        N = int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 901))
+        d = int(rng.choice([8, 16, 24, 32, 40, 64, 72, 96, 104, 128])) if rng.random() < 0.6 else int(rng.integers(1, 129))
+        kt = fa.KernelType(int(rng.integers(0, 12)))
+        if not allowed(fa, kt, d):
+            continue
+        mode = int(rng.integers(0, 3))          # 0 fp16, 1 fp32, 2 fp32 with workspace
+        scale = float(rng.choice([0.25, 0.5, 1.0]))
+        q, k, v = (oracle.round_f16((rng.standard_normal((B, H, N, d)) * scale).astype(np.float32)) for _ in range(3))
+        ref = oracle.attn_naive(q, k, v)
+        o = run_abi(fa, torch, q, k, v, kt, torch.float16 if mode == 0 else torch.float32, workspace=(mode == 2))
+        assert_close(o, ref, f"fuzz case {done}: {(B, H, N, d)} {kt.name} mode {mode} scale {scale}")
+        done += 1
+
+
 def test_forced_rescale_spike(fa, oracle, torch_gpu):
     """A key that dominates a query row late in the sweep forces the online-softmax rescale (the
     running max jumps by far more than any deferral threshold) at chosen tiles."""
