@@ -266,6 +266,30 @@ def test_python_wrapper_matches_reference_semantics(fa, oracle, torch_gpu):
         fa.forward(q[..., :31].contiguous(), k[..., :31].contiguous(), v[..., :31].contiguous(), fa.KernelType.mma_qreg)
 
 
+def test_entry_point_is_capturable_in_a_hip_graph(fa, oracle, torch_gpu):
+    """The C ABI only enqueues work on the caller's stream (no allocation, no synchronisation), so a call
+    can be recorded into a HIP graph and replayed on new data in the same buffers."""
+    torch = torch_gpu
+    shape = (2, 3, 512, 128)
+    rng = np.random.default_rng(5)
+    host = [oracle.round_f16(rng.standard_normal(shape).astype(np.float32)) for _ in range(6)]
+    q, k, v = (torch.from_numpy(x).to("cuda:0", torch.float16) for x in host[:3])
+    o = torch.empty_like(q)
+    fa.forward(q, k, v, out=o)                     # first call on the device sets the kernel's LDS attribute
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            fa.forward(q, k, v, out=o, sync=False)
+    for base in (0, 3):
+        for t, x in zip((q, k, v), host[base:base + 3]):
+            t.copy_(torch.from_numpy(x).to("cuda:0", torch.float16))
+        o.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert_close(o.float().cpu().numpy(), oracle.attn_naive(*host[base:base + 3]), f"graph replay, inputs {base}")
+
+
 def test_native_selftest_binary(fa):
     """The torch-free harness (tests/native/selftest.cpp) passes on this GPU."""
     exe = os.path.join(fa.REPO_ROOT, "tests", "native", "selftest")
