@@ -18,6 +18,7 @@ Rows
   torch_flash_v2     torch.nn.functional.scaled_dot_product_attention in fp16 (whatever backend
                      PyTorch-ROCm selects)
   mma_qreg_async_fp32  the same op on fp32 tensors (conversion pass into scratch + fp16 kernel, fp32 out)
+  mma_qreg_async_bf16  the same op on bfloat16 tensors
 
   python benchmarks/sweep.py [--out profiles/sweep.json] [--max-n 16384] [--reps 10]
 """
@@ -66,6 +67,8 @@ def main():
         ("torch_flash_v2", F.scaled_dot_product_attention),
         # the reference's own tensor dtype: fp32 in, fp32 out (conversion pass + fp16 kernel)
         ("mma_qreg_async_fp32", lambda q, k, v: pyflash.mma_qreg_async(q32, k32, v32)),
+        # bfloat16 tensors: the same kernels with bfloat16 matrix instructions
+        ("mma_qreg_async_bf16", lambda q, k, v: pyflash.mma_qreg_async(qb, kb, vb)),
     ]
 
     def time_ms(fn, q, k, v):
@@ -90,6 +93,7 @@ def main():
     for N in seqs:
         q, k, v = (torch.randn(B, H, N, d, device=dev, generator=gen).half() for _ in range(3))
         q32, k32, v32 = q.float(), k.float(), v.float()
+        qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
         flops = 4.0 * B * H * N * N * d
         print(f"\nseq_len {N}", flush=True)
         ref = None
@@ -108,7 +112,7 @@ def main():
         if ref is not None:
             err = float((pyflash.mma_qreg_async(q, k, v).float() - ref.float()).abs().max())
             print(f"  max |native - torch SDPA| = {err:.2e}")
-        del q, k, v, q32, k32, v32
+        del q, k, v, q32, k32, v32, qb, kb, vb
         torch.cuda.empty_cache()
 
     print()

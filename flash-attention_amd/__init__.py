@@ -66,7 +66,7 @@ class LaunchInfo:
 
 # every symbol include/flash_hip.h declares
 ABI_SYMBOLS = (
-    "flash_fwd_f16", "flash_fwd_f32", "flash_fwd_f32_ws", "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
+    "flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_ws", "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
     "flash_kernel_type_name",
     "flash_hip_last_error", "flash_hip_version",
 )
@@ -89,7 +89,7 @@ def lib() -> ctypes.CDLL:
 
     L = ctypes.CDLL(LIB_PATH)
     i64, vp = ctypes.c_int64, ctypes.c_void_p
-    for name in ("flash_fwd_f16", "flash_fwd_f32"):
+    for name in ("flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32"):
         fn = getattr(L, name)
         fn.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_int, vp]
         fn.restype = ctypes.c_int
@@ -140,7 +140,8 @@ def launch_info(B: int, H: int, N: int, d: int, kernel_type=KernelType.mma_qreg_
 def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: bool = True):
     """Counterpart of ``flash::forward(Q, K, V, kernel_type)`` (flash/launch.hpp:23-24).
 
-    Q, K, V: 4-D ``[B, H, N, d]`` tensors on a HIP device, fp16 (native) or fp32 (the reference's
+    Q, K, V: 4-D ``[B, H, N, d]`` tensors on a HIP device, fp16 (native), bf16 (same kernels with
+    bfloat16 matrix instructions, d a multiple of 8) or fp32 (the reference's
     dtype; rounded to fp16 by one conversion pass into per-call scratch, or inside the kernel when
     d is not a multiple of 8; result returned as fp32).  Returns a new tensor O of
     the shape and dtype of Q.  Like the reference (flash/launch.cu:320-321) the call blocks until
@@ -154,8 +155,8 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
         raise ValueError("K and V must have the shape of Q")
     if not Q.is_cuda or K.device != Q.device or V.device != Q.device:
         raise ValueError("Q, K, V must live on the same HIP device (there is no CPU path)")
-    if Q.dtype not in (torch.float16, torch.float32) or K.dtype != Q.dtype or V.dtype != Q.dtype:
-        raise ValueError("Q, K, V must all be float16 or all be float32")
+    if Q.dtype not in (torch.float16, torch.bfloat16, torch.float32) or K.dtype != Q.dtype or V.dtype != Q.dtype:
+        raise ValueError("Q, K, V must all be float16, all bfloat16 or all float32")
     Q, K, V = Q.contiguous(), K.contiguous(), V.contiguous()
     B, H, N, d = Q.shape
     if out is None:
@@ -166,9 +167,9 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
     with torch.cuda.device(Q.device):
         stream = torch.cuda.current_stream(Q.device)
         sp = ctypes.c_void_p(stream.cuda_stream)
-        if Q.dtype == torch.float16:
-            rc = lib().flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d,
-                                     scale, int(kernel_type), sp)
+        if Q.dtype in (torch.float16, torch.bfloat16):
+            fn = lib().flash_fwd_f16 if Q.dtype == torch.float16 else lib().flash_fwd_bf16
+            rc = fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d, scale, int(kernel_type), sp)
         else:
             # scratch for the fp16 copies of Q, K, V (the reference allocates per-call scratch too,
             # flash/launch.cu:150-157); torch's allocator re-issues the block in stream order

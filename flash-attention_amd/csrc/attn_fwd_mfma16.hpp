@@ -67,33 +67,73 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * Cfg<D>::kRowBytes + ((chunk ^ swz<D>(row)) << 4);
 }
 
+// Operand element kind of the matrix instructions: IEEE binary16 or bfloat16.  Registers that hold
+// packed 16-bit operands are typed f16x8 / f16x4v in both cases (bit containers); only the instruction
+// mnemonics and the float <-> 16-bit conversions differ.
+constexpr int kF16 = 0;
+constexpr int kBF16 = 1;
+struct bf16_out {  // tag type: O is written as bfloat16
+  uint16_t bits;
+};
+
 // S^T tile: first k-step takes srcC from `c0` (the bias registers or 0), later ones accumulate.
+template <int EK = kF16>
 __device__ __forceinline__ void mfma_s_first(f32x4& acc, const f16x8& a, const f16x8& b, const f32x4& c0) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c0));
-}
-__device__ __forceinline__ void mfma_s_first0(f32x4& acc, const f16x8& a, const f16x8& b) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
-}
-template <bool PAD>
-__device__ __forceinline__ void mfma_s(f32x4& acc, const f16x8& a, const f16x8& b) {
-  if constexpr (PAD) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+  if constexpr (EK == kBF16) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c0));
   } else {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c0));
   }
 }
-template <bool PAD>
-__device__ __forceinline__ void mfma_o(f32x4& acc, const f16x8& a, const f16x8& b) {
-  if constexpr (PAD) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+template <int EK = kF16>
+__device__ __forceinline__ void mfma_s_first0(f32x4& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (EK == kBF16) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
   } else {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+  }
+}
+template <bool PAD, int EK = kF16>
+__device__ __forceinline__ void mfma_s(f32x4& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (EK == kBF16) {
+    if constexpr (PAD) {
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+    } else {
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+    }
+  } else {
+    if constexpr (PAD) {
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+    } else {
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+    }
+  }
+}
+template <bool PAD, int EK = kF16>
+__device__ __forceinline__ void mfma_o(f32x4& acc, const f16x8& a, const f16x8& b) {
+  if constexpr (EK == kBF16) {
+    if constexpr (PAD) {
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    } else {
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+  } else {
+    if constexpr (PAD) {
+      asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    } else {
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
   }
 }
 
 // First P V product of a work item: srcC is the constant 0, so the accumulators need no clearing.
+template <int EK = kF16>
 __device__ __forceinline__ void mfma_o_first0(f32x4& acc, const f16x8& a, const f16x8& b) {
-  asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+  if constexpr (EK == kBF16) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+  } else {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+  }
 }
 
 // What the P V slots of a pipeline step do
@@ -107,9 +147,31 @@ constexpr int kPvFirst = 2;       // O  = V^T P^T (first product of an item)
 // sum of the lane's own four fp16 values, accumulated in fp32: one 2-pass MFMA replaces the vector adds
 // of four probabilities, exactly.
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+template <int EK = kF16>
 __device__ __forceinline__ void mfma_rowsum(f32x4& acc, const f16x4v& ones, const f16x4v& p4) {
-  asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(ones), "v"(p4));
+  if constexpr (EK == kBF16) {
+    asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(ones), "v"(p4));
+  } else {
+    asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(ones), "v"(p4));
+  }
 }
+
+// Two floats to one register of packed 16-bit values of kind EK, round to nearest even
+// (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int EK>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  const f32x2_t x = {lo, hi};
+  if constexpr (EK == kBF16) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf16x2_t));
+  } else {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(x, f16x2));
+  }
+}
+// 1.0 in both halves
+template <int EK>
+constexpr uint32_t kOnes2 = EK == kBF16 ? 0x3F803F80u : 0x3C003C00u;
 
 // Wait states for the last MFMAs, with the accumulators as operands so that their readers stay
 // behind the wait.  The statements are volatile, hence ordered among themselves: the first one
@@ -218,7 +280,7 @@ __device__ __forceinline__ void mask_tile(f32x4& s, int kv_tile0, int N, int lan
 // One pipeline step: QK(j+1) (32 MFMAs), PV(j-1) (32 MFMAs), exp(j), in-lane max(j+1).
 //   s_cur/s_nxt[kb][q]: S^T tiles of key block kb (16 keys) and query block q (16 queries)
 //   p_prev/p_cur[q]:    P^T fragments (32 keys) of query block q
-template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, int PV_MODE = kPvAccumulate, typename Hook>
+template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, int PV_MODE = kPvAccumulate, int EK = kF16, typename Hook>
 __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off, uint32_t vb_off, uint32_t kb_next_off,
                                               const LaneAddr<D>& la, const f32x4 (&bias)[kQ16],
                                               const f16x8 (&qf)[kQ16][Cfg<D>::kKS], f16x8 (&ka)[4],
@@ -241,9 +303,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
 
   // exp(j), software-pipelined over the slots.  Element g = 8q + e: key block e / 4, register e % 4.
   float t_exp = 0.f, t_exp_prev = 0.f;
-  f16x4v ones4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ones4[j] = (f16)1.f;
+  f16x4v ones4 = __builtin_bit_cast(f16x4v, u32x2{kOnes2<EK>, kOnes2<EK>});
   asm volatile("" : "+v"(ones4));
   auto pin = [](f16x2& x) __attribute__((always_inline)) {
     uint32_t w = __builtin_bit_cast(uint32_t, x);
@@ -259,15 +319,13 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     } else {
       p4 = __builtin_shufflevector(p_cur[q], p_cur[q], 4, 5, 6, 7);
     }
-    mfma_rowsum(lsum[q], ones4, p4);
+    mfma_rowsum<EK>(lsum[q], ones4, p4);
   };
   auto finish = [&](int g) __attribute__((always_inline)) {
     const int q = g / 8, e = g % 8;
     if ((g & 3) == 1 && g >= 5) group_add(g / 4 - 1);
     if ((g & 1) != 0) {
-      f16x2 w;
-      w[0] = (f16)t_exp_prev;
-      w[1] = (f16)t_exp;
+      f16x2 w = __builtin_bit_cast(f16x2, pack2<EK>(t_exp_prev, t_exp));
       pin(w);
       p_cur[q][e - 1] = w[0];
       p_cur[q][e] = w[1];
@@ -314,9 +372,9 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
       const int kb = f / kKS, ks = f % kKS;
       if constexpr (HAS_QK) {
         if (ks == 0) {
-          mfma_s_first(s_nxt[kb][q], ka[f % 4], qf[q][ks], bias[q]);
+          mfma_s_first<EK>(s_nxt[kb][q], ka[f % 4], qf[q][ks], bias[q]);
         } else {
-          mfma_s<false>(s_nxt[kb][q], ka[f % 4], qf[q][ks]);
+          mfma_s<false, EK>(s_nxt[kb][q], ka[f % 4], qf[q][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (q == kQ16 - 1) {
@@ -344,9 +402,9 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     for (int q = 0; q < kQ16; ++q) {
       const int pslot = b * kQ16 + q;
       if constexpr (PV_MODE == kPvFirst) {
-        mfma_o_first0(o[q][b], va[b % 4], p_prev[q]);
+        mfma_o_first0<EK>(o[q][b], va[b % 4], p_prev[q]);
       } else if constexpr (PV_MODE == kPvAccumulate) {
-        mfma_o<false>(o[q][b], va[b % 4], p_prev[q]);
+        mfma_o<false, EK>(o[q][b], va[b % 4], p_prev[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (PV_MODE != kPvSkip && q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
@@ -438,6 +496,14 @@ template <>
 struct OutStores<float> {
   static constexpr int per_block(int dv16) { return dv16; }
 };
+template <>
+struct OutStores<bf16_out> {
+  static constexpr int per_block(int dv16) { return dv16 / 2; }
+};
+// operand element kind that goes with an output type (bfloat16 in -> bfloat16 out; fp32 callers feed
+// fp16 copies)
+template <typename TO>
+constexpr int kElemKindOf = std::is_same<TO, bf16_out>::value ? kBF16 : kF16;
 
 template <int NB, typename TO>
 __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, uint32_t qrow, int d, int g,
@@ -447,8 +513,9 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
     for (int b = 0; b < NB; b += 2) {
       // packed multiplies, then packed conversions: the pairs come out in the layout the stores need
       const f32x4 xs = oq[b] * inv, ys = oq[b + 1] * inv;
-      const f16x4 x = __builtin_convertvector(xs, f16x4), y = __builtin_convertvector(ys, f16x4);
-      const u32x2 xu = __builtin_bit_cast(u32x2, x), yu = __builtin_bit_cast(u32x2, y);
+      constexpr int EK = kElemKindOf<TO>;
+      const u32x2 xu = {pack2<EK>(xs[0], xs[1]), pack2<EK>(xs[2], xs[3])};
+      const u32x2 yu = {pack2<EK>(ys[0], ys[1]), pack2<EK>(ys[2], ys[3])};
       u32x4 out;
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
@@ -474,10 +541,27 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
   }
 }
 
+// One register of two packed Q values times softmax_scale * log2(e), rounded once to 16 bits.
+//  fp16: v_fma_mix reads the halves as fp16, multiplies in fp32 and rounds back (two instructions);
+//  bf16: the halves are widened by shifts / masks, multiplied in fp32 and packed by v_cvt_pk_bf16_f32.
+template <int EK>
+__device__ __forceinline__ uint32_t scale_q2(uint32_t x, float sc) {
+  if constexpr (EK == kBF16) {
+    return pack2<kBF16>(__uint_as_float(x << 16) * sc, __uint_as_float(x & 0xFFFF0000u) * sc);
+  } else {
+    asm("v_fma_mixlo_f16 %0, %0, %1, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %0, %1, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(x)
+        : "v"(sc));
+    return x;
+  }
+}
+
 template <int D, typename TO = f16>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = Cfg<D>;
+  constexpr int EK = kElemKindOf<TO>;
   constexpr int kKS = C::kKS, kDv16 = C::kDv16, kTileBytes = C::kTileBytes, kBlkBytes = C::kBlkBytes;
   constexpr int kPiecesPerWave = C::kPiecesPerWave;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -569,8 +653,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) {
+      u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
+      for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], p.scale_log2e);
+      qf[q][ks] = __builtin_bit_cast(f16x8, w);
     }
   }
   f32x4 o[kQ16][kDv16];
@@ -606,9 +692,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
       if (f % kKS == 0) {
-        mfma_s_first0(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+        mfma_s_first0<EK>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
       } else {
-        mfma_s<true>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+        mfma_s<true, EK>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
       }
     }
     if (f + 4 < 2 * kKS) {
@@ -669,10 +755,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const uint32_t k_nxt = (uint32_t)(s1 * kTileBytes);
     const uint32_t v_cur = (uint32_t)(s0 * kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * kTileBytes);
-    pipeline_step<D, true, !LAST, MASKED>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
+    pipeline_step<D, true, !LAST, MASKED, kPvAccumulate, EK>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
                                        pB, pA, st, lsum, t * kBc + 32, N, lane);
     step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
-    pipeline_step<D, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
+    pipeline_step<D, !LAST, !LAST, MASKED, kPvAccumulate, EK>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
                                         lsum, (t + 1) * kBc, N, lane);
     step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
     staged_barrier();
@@ -697,7 +783,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     for (int b = 0; b < kDv16; ++b) {
       const f16x8 vf = read_v<D>(vb, la, b);
 #pragma unroll
-      for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
+      for (int q = 0; q < kQ16; ++q) mfma_o<true, EK>(o[q][b], vf, pB[q]);
     }
     drain_o(o);
     drain_lsum(lsum);
@@ -758,6 +844,7 @@ template <int D, typename TO = f16>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = CfgP<D>;
+  constexpr int EK = kElemKindOf<TO>;
   constexpr int kKS = C::kKS, kDv16 = C::kDv16, kTileBytes = C::kTileBytes, kBlkBytes = C::kBlkBytes;
   constexpr int kPiecesPerWave = C::kPiecesPerWave;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -841,7 +928,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
   };
   // pre-multiply by softmax_scale * log2(e); the registers come back as accumulation registers
-  // (v_fma_mix: fp16 halves in, fp32 product, one rounding back to fp16 -- two instructions per register)
   auto convert_q = [&]() __attribute__((always_inline)) {
     const float sc = p.scale_log2e;
 #pragma unroll
@@ -850,14 +936,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       for (int ks = 0; ks < kKS; ++ks) {
         u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint32_t x = w[j];
-          asm("v_fma_mixlo_f16 %0, %0, %1, 0 op_sel_hi:[1,0,0]\n\t"
-              "v_fma_mixhi_f16 %0, %0, %1, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-              : "+v"(x)
-              : "v"(sc));
-          w[j] = x;
-        }
+        for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], sc);
         qf[q][ks] = __builtin_bit_cast(f16x8, w);
         asm volatile("" : "+a"(qf[q][ks]));
       }
@@ -909,9 +988,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 #pragma unroll
       for (int q = 0; q < kQ16; ++q) {
         if (f % kKS == 0) {
-          mfma_s_first0(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+          mfma_s_first0<EK>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
         } else {
-          mfma_s<true>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
+          mfma_s<true, EK>(sA[f / kKS][q], ka[f % 4], qf[q][f % kKS]);
         }
       }
       if (f + 4 < 2 * kKS) {
@@ -981,7 +1060,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       };
       constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
       constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
-      pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate>(
+      pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate, EK>(
           dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, st, lsum, 0, N, lane);
       step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
       if constexpr (LAST) {
@@ -989,7 +1068,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         // loads have the last step, the last P V product and the output stores to land.
         if (has_next) fetch_q(next_item);
       }
-      pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate>(
+      pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate, EK>(
           no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st, lsum, 0, N, lane);
       step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
       if constexpr (LAST) {
@@ -1028,7 +1107,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       for (int b = 0; b < kDv16; ++b) {
         const f16x8 vf = read_v<D>(vb, la, b);
 #pragma unroll
-        for (int q = 0; q < kQ16; ++q) mfma_o<true>(o[q][b], vf, pB[q]);
+        for (int q = 0; q < kQ16; ++q) mfma_o<true, EK>(o[q][b], vf, pB[q]);
       }
       drain_o(o);
       drain_lsum(lsum);

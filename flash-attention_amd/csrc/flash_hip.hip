@@ -239,6 +239,28 @@ int flash_fwd_f32(const void* q, const void* k, const void* v, void* o, int64_t 
   return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
 }
 
+int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                   float softmax_scale, int kernel_type, void* hip_stream) {
+  Plan plan;
+  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
+  if (rc != FLASH_HIP_OK) return rc;
+  if (!plan.fast)
+    return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
+                (long long)d);
+  if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
+  FwdParams prm;
+  prm.q = q;
+  prm.k = k;
+  prm.v = v;
+  prm.o = o;
+  prm.N = (int)N;
+  prm.d = (int)d;
+  prm.nqt = (int)plan.nqt;
+  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
+  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  return launch_fast<m16::bf16_out>(prm, plan, N, (hipStream_t)hip_stream);
+}
+
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type) {
   Plan plan;
   if (make_plan(B, H, N, d, kernel_type, true, &plan) != FLASH_HIP_OK) return -1;

@@ -23,8 +23,8 @@ void check_inputs(const torch::Tensor& Q, const torch::Tensor& K, const torch::T
   TORCH_CHECK(K.sizes() == Q.sizes() && V.sizes() == Q.sizes(), "flash::forward: K and V must have the shape of Q");
   TORCH_CHECK(Q.is_cuda() && K.is_cuda() && V.is_cuda(), "flash::forward: tensors must be on a HIP device");
   TORCH_CHECK(K.device() == Q.device() && V.device() == Q.device(), "flash::forward: tensors on different devices");
-  TORCH_CHECK(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kFloat,
-              "flash::forward: dtype must be float16 or float32");
+  TORCH_CHECK(Q.scalar_type() == at::kHalf || Q.scalar_type() == at::kBFloat16 || Q.scalar_type() == at::kFloat,
+              "flash::forward: dtype must be float16, bfloat16 or float32");
   TORCH_CHECK(K.scalar_type() == Q.scalar_type() && V.scalar_type() == Q.scalar_type(),
               "flash::forward: Q, K, V must share one dtype");
 }
@@ -56,6 +56,9 @@ torch::Tensor run(torch::Tensor Q, torch::Tensor K, torch::Tensor V, KernelType 
   if (Q.scalar_type() == at::kHalf) {
     rc = flash_fwd_f16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale, kt,
                        stream.stream());
+  } else if (Q.scalar_type() == at::kBFloat16) {
+    rc = flash_fwd_bf16(Q.data_ptr(), K.data_ptr(), V.data_ptr(), O.data_ptr(), B, H, N, d, softmax_scale, kt,
+                        stream.stream());
   } else {
     // fp32 tensors, the reference's own dtype (flash/launch.cu:165-176): per-call scratch for the fp16
     // copies of Q, K, V, as the reference allocates l and m per call (launch.cu:150-157).  The block

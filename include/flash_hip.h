@@ -85,6 +85,19 @@ int flash_fwd_f16(const void* q, const void* k, const void* v, void* o,
                   float softmax_scale, int kernel_type, void* hip_stream);
 
 /*
+ * bfloat16 attention forward: the same kernels as flash_fwd_f16 with bfloat16 operands on the matrix
+ * cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation, bfloat16 output.  No counterpart in the
+ * reference (its tensors are fp32, flash/launch.cu:165-176); offered because bfloat16 is the usual
+ * storage type of the models this shape comes from.  d must be a multiple of 8 (-> UNSUPPORTED_DIM
+ * otherwise); other errors as flash_fwd_f16.  P and Q * softmax_scale are rounded to 8 mantissa bits,
+ * so the error against an fp32 evaluation on the same inputs is several times that of fp16
+ * (measured max-abs 1e-3 ... 4.4e-3 on standard-normal data).
+ */
+int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o,
+                   int64_t B, int64_t H, int64_t N, int64_t d,
+                   float softmax_scale, int kernel_type, void* hip_stream);
+
+/*
  * fp32 attention forward for the reference's fp32 callers (main.cpp:30-32, benchmarks/bench.py:34-36
  * hand fp32 tensors to flash::forward, which reads them with data_ptr<float>(), launch.cu:165-176).
  * Q, K, V are rounded to fp16 (round-to-nearest-even) while they are staged into LDS/registers, the

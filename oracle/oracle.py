@@ -71,6 +71,14 @@ def round_f16(x) -> np.ndarray:
     return out
 
 
+def round_bf16(x) -> np.ndarray:
+    """fp32 -> bfloat16 -> fp32, round to nearest even (what torch's .bfloat16() does); pure numpy."""
+    a = _f32(x)
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
 def attn_naive(q, k, v, scale: float | None = None) -> np.ndarray:
     """softmax(q k^T * scale) v in fp32, q/k/v of shape [B, H, N, d] (reference main.cpp:12-17)."""
     q, k, v = _f32(q), _f32(k), _f32(v)

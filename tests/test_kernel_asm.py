@@ -56,7 +56,7 @@ def main_loop(lines, min_mfma=90):
 
 def test_no_kernel_spills(asm_text):
     names = re.findall(r"\.name:\s+(_ZN9flash_hip\S*attn_fwd_kernel\S*)", asm_text)
-    assert len(names) >= 10, names
+    assert len(names) >= 14, names
     vals = re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm_text)
     assert vals and all(v == "0" for v in vals), vals
     # scalar registers may overflow into lanes of a vector register (the persistent d=128 kernel keeps
@@ -77,14 +77,17 @@ TUNED = {
 
 @pytest.mark.parametrize("frag", sorted(TUNED))
 def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
-    # two instantiations each: O written as fp16 and as fp32 (same loops, different epilogues)
+    # three instantiations each: fp16 in/out, bfloat16 in/out, fp16 in with O written as fp32 (same loop
+    # structure, different matrix-instruction mnemonics and epilogues)
     ks = {n: l for n, l in kernels(asm_text).items() if frag in n}
-    assert len(ks) == 2, list(ks)
+    assert len(ks) == 3, list(ks)
     for name, lines in ks.items():
         per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
         loop = main_loop(lines, TUNED[frag][0] - per_step)
         assert loop is not None, f"{name}: main loop not found"
         n_mfma = sum("v_mfma_f32_16x16x32" in l for l in loop)   # the 4x4x4 row-sum MFMAs come on top
+        want = "v_mfma_f32_16x16x32_bf16" if "bf16_out" in name else "v_mfma_f32_16x16x32_f16"
+        assert all(want in l for l in lines if "v_mfma_f32_16x16x32" in l), f"{name}: mixed operand kinds"
         assert n_mfma in (TUNED[frag][0], TUNED[frag][0] - per_step), (name, n_mfma)
         if "m16p" in frag:
             # the cold rescale blocks of the persistent kernels are laid out inside the loop's address

@@ -75,3 +75,13 @@ def test_edge_single_key_and_uniform(oracle):
     z = np.zeros_like(v)
     o = oracle.attn_tiled(z, v, v, Br=8, Bc=8)
     np.testing.assert_allclose(o, np.broadcast_to(v.mean(axis=2, keepdims=True), v.shape), rtol=1e-5, atol=1e-6)
+
+
+def test_bf16_rounding_matches_torch(oracle):
+    import torch
+
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(4096).astype(np.float32) * 3.0,
+                        np.float32([0.0, -0.0, 1.0, 1.00390625, 1.0078125, 65504.0, 1e-30, -3.3e38])])
+    want = torch.from_numpy(x).bfloat16().float().numpy()
+    assert np.array_equal(oracle.round_bf16(x), want)
