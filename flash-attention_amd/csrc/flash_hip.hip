@@ -81,6 +81,22 @@ int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool 
 }
 
 
+// Kernel arguments of one call.  The kernels work in the exp2 domain: the softmax scale carries log2(e).
+FwdParams make_params(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                      float softmax_scale, const Plan& plan) {
+  FwdParams prm{};
+  prm.q = q;
+  prm.k = k;
+  prm.v = v;
+  prm.o = o;
+  prm.N = (int)N;
+  prm.d = (int)d;
+  prm.nqt = (int)plan.nqt;
+  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
+  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  return prm;
+}
+
 template <typename Kernel>
 int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16],
                   uint32_t grid = 0) {
@@ -202,16 +218,7 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   int rc = make_plan(B, H, N, d, kernel_type, sizeof(T) == 2, &plan);
   if (rc != FLASH_HIP_OK) return rc;
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  FwdParams prm;
-  prm.q = q;
-  prm.k = k;
-  prm.v = v;
-  prm.o = o;
-  prm.N = (int)N;
-  prm.d = (int)d;
-  prm.nqt = (int)plan.nqt;
-  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
-  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan);
   hipStream_t stream = (hipStream_t)hip_stream;
   if constexpr (sizeof(T) == 2) {
     if (plan.fast) {
@@ -248,16 +255,7 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
     return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
                 (long long)d);
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  FwdParams prm;
-  prm.q = q;
-  prm.k = k;
-  prm.v = v;
-  prm.o = o;
-  prm.N = (int)N;
-  prm.d = (int)d;
-  prm.nqt = (int)plan.nqt;
-  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
-  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan);
   return launch_fast<m16::bf16_out>(prm, plan, N, (hipStream_t)hip_stream);
 }
 
@@ -294,16 +292,7 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64
   hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, cp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
-  FwdParams prm;
-  prm.q = cp.dst[0];
-  prm.k = cp.dst[1];
-  prm.v = cp.dst[2];
-  prm.o = o;
-  prm.N = (int)N;
-  prm.d = (int)d;
-  prm.nqt = (int)plan.nqt;
-  prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
-  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  const FwdParams prm = make_params(cp.dst[0], cp.dst[1], cp.dst[2], o, B, H, N, d, softmax_scale, plan);
   return launch_fast<float>(prm, plan, N, stream);
 }
 
