@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--kernel-type", default="mma_qreg_async")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
                     help="tensor type; the metric is defined on fp16, bf16 runs the same kernels with bfloat16 "
-                         "matrix instructions (parity is then checked against the bf16 bar of 8e-3)")
+                         "matrix instructions (parity is then checked against the bf16 bar of 1.6e-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo lets several ranks rehearse the "
@@ -248,7 +248,7 @@ def main():
             hq, hk, hv = (x[B - 1:B, H - 1:H].float().cpu().numpy() for x in (q, k, v))
             ref = orc.attn_naive(hq, hk, hv)
             err = float(np.abs(o[B - 1, H - 1].float().cpu().numpy() - ref[0, 0]).max())
-            bar = 2e-3 if args.dtype == "fp16" else 8e-3
+            bar = 2e-3 if args.dtype == "fp16" else 1.6e-2
             line["parity"] = {"max_abs_vs_cpu_oracle": err, "bar": bar, "ok": bool(err <= bar)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(orc, shape)

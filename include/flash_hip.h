@@ -91,7 +91,7 @@ int flash_fwd_f16(const void* q, const void* k, const void* v, void* o,
  * storage type of the models this shape comes from.  d must be a multiple of 8 (-> UNSUPPORTED_DIM
  * otherwise); other errors as flash_fwd_f16.  P and Q * softmax_scale are rounded to 8 mantissa bits,
  * so the error against an fp32 evaluation on the same inputs is several times that of fp16
- * (measured max-abs 1e-3 ... 4.4e-3 on standard-normal data).
+ * (measured max-abs 1e-3 ... 7.4e-3 on standard-normal data; tested against 1.6e-2).
  */
 int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o,
                    int64_t B, int64_t H, int64_t N, int64_t d,

@@ -2,8 +2,9 @@
 
 Not part of the reference (its tensors are fp32).  Bar, stated here because bfloat16 keeps 8 mantissa
 bits where fp16 keeps 11: against the fp32 CPU oracle evaluated on the bfloat16-rounded inputs,
-max-abs <= 8e-3 and |res - ref| <= 8e-3 + 2e-2 |ref| (four times the fp16 bar; P, Q * scale and O are
-rounded to bfloat16; measured 1e-3 ... 4.4e-3 on standard-normal data).
+max-abs <= 1.6e-2 and |res - ref| <= 1.6e-2 + 2e-2 |ref| (eight times the fp16 bar, for the three mantissa
+bits less; P, Q * scale and O are rounded to bfloat16).  Measured on standard-normal data: 1e-3 ... 4.4e-3
+on the shapes below, 7.4e-3 worst over a few hundred random shapes.
 """
 import ctypes
 
@@ -12,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ATOL_BF16 = 8e-3
+ATOL_BF16 = 1.6e-2
 RTOL_BF16 = 2e-2
 
 SHAPES = [(2, 3, 512, 128), (1, 4, 1024, 64), (2, 2, 333, 128), (1, 3, 100, 72), (3, 5, 256, 64), (1, 2, 65, 8),
@@ -57,7 +58,7 @@ def test_bf16_forced_rescale_and_wrapper(fa, oracle):
     ref = oracle.attn_naive(q, k, v)
     o = run_bf16(fa, torch, q, k, v)
     err = np.abs(o - ref)
-    assert err.max() <= 2 * ATOL_BF16 and (err <= 2 * ATOL_BF16 + RTOL_BF16 * np.abs(ref)).all(), err.max()
+    assert err.max() <= ATOL_BF16 and (err <= ATOL_BF16 + RTOL_BF16 * np.abs(ref)).all(), err.max()
     # the Python wrapper: bfloat16 in, bfloat16 out
     tq, tk, tv = (torch.from_numpy(x).cuda().bfloat16() for x in (q, k, v))
     o2 = fa.forward(tq, tk, tv)
