@@ -252,7 +252,8 @@ def head_chunks(per_rank: int, chunks: int):
 
 
 def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mma_qreg_async, *,
-                         chunks: int = 4, group=None, sync: bool = True, out=None, compute=None):
+                         chunks: int = 4, group=None, sync: bool = True, out=None, compute=None,
+                         exchange: str = "p2p"):
     """Forward of this rank's slab with the output all-gather overlapped with the attention kernels.
 
     The slab is cut into ``chunks`` ranges of heads.  Each range is computed straight into its final
@@ -265,6 +266,12 @@ def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mm
     valid; there is no collective inside the attention itself.  The slab layout is the one of
     :func:`shard_heads`: rank r owns flattened heads [r*per, r*per + heads_local), per =
     ceil(total_heads / world); ranks may own fewer heads than ``per`` (or none).
+
+    ``exchange`` selects how a range travels.  ``"p2p"`` (default): every rank sends its range to every
+    peer and receives the peers' ranges straight into their final places, as one batch of point-to-point
+    operations -- on a node whose GPUs are fully connected by point-to-point xGMI links every transfer
+    has a link of its own, and nothing is staged or copied.  ``"all_gather"``: one all-gather per range
+    on a list of output views (the process group gathers into a flat buffer and copies from there).
 
     ``out`` may hold a preallocated ``[world * per, N, d]`` buffer (reused from step to step).
     ``compute(q, k, v, out)`` replaces the kernel call; it exists for hosts without a GPU (CPU tests
@@ -302,7 +309,18 @@ def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mm
         if n_own < c1 - c0:
             mine[n_own:].zero_()  # padding rows of a short slab
         views = [full[g * per + c0: g * per + c1] for g in range(world)]
-        works.append(dist.all_gather(views, mine, group=group, async_op=True))
+        if world == 1:
+            continue
+        if exchange == "all_gather":
+            works.append(dist.all_gather(views, mine, group=group, async_op=True))
+        elif exchange == "p2p":
+            peers = [g for g in range(world) if g != rank]
+            to_global = (lambda g: g) if group is None else (lambda g: dist.get_global_rank(group, g))
+            ops = [dist.P2POp(dist.isend, mine, to_global(g), group) for g in peers]
+            ops += [dist.P2POp(dist.irecv, views[g], to_global(g), group) for g in peers]
+            works.extend(dist.batch_isend_irecv(ops))
+        else:
+            raise ValueError("exchange must be 'p2p' or 'all_gather'")
     for w in works:
         w.wait()
     if sync and full.is_cuda:

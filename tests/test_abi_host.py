@@ -153,10 +153,11 @@ assert torch.allclose(o_full, want, atol=1e-6), (o_full - want).abs().max()
 def cpu_kernel(qc, kc, vc, out):
     out.copy_(torch.from_numpy(orc.attn_naive(qc.numpy()[None], kc.numpy()[None], vc.numpy()[None])[0]))
 tq, tk, tv = (torch.from_numpy(x[a:b]) for x in (q, k, v))
-for chunks in (1, 2, 3, 8):
-    got = fa.forward_shard_gather(tq, tk, tv, B * H, chunks=chunks, compute=cpu_kernel)
-    assert got.shape == want.shape
-    assert torch.allclose(got, want, atol=1e-6), (chunks, (got - want).abs().max())
+for exchange in ("p2p", "all_gather"):
+    for chunks in (1, 2, 3, 8):
+        got = fa.forward_shard_gather(tq, tk, tv, B * H, chunks=chunks, compute=cpu_kernel, exchange=exchange)
+        assert got.shape == want.shape
+        assert torch.allclose(got, want, atol=1e-6), (exchange, chunks, (got - want).abs().max())
 try:
     fa.forward_shard_gather(tq[:1], tk[:1], tv[:1], B * H, compute=cpu_kernel)
     raise SystemExit("a slab of the wrong size was accepted")
