@@ -309,12 +309,12 @@ def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mm
         if n_own < c1 - c0:
             mine[n_own:].zero_()  # padding rows of a short slab
         views = [full[g * per + c0: g * per + c1] for g in range(world)]
-        if world == 1:
-            continue
         if exchange == "all_gather":
             works.append(dist.all_gather(views, mine, group=group, async_op=True))
         elif exchange == "p2p":
             peers = [g for g in range(world) if g != rank]
+            if not peers:
+                continue
             to_global = (lambda g: g) if group is None else (lambda g: dist.get_global_rank(group, g))
             ops = [dist.P2POp(dist.isend, mine, to_global(g), group) for g in peers]
             ops += [dist.P2POp(dist.irecv, views[g], to_global(g), group) for g in peers]

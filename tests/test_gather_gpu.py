@@ -32,10 +32,12 @@ for (heads, N, d) in ((7, 512, 128), (5, 320, 64), (3, 100, 68)):
     ref = orc.attn_naive(*(x[None].float().cpu().numpy() for x in (q, k, v)))[0]
     err = np.abs(plain.float().cpu().numpy() - ref)
     assert err.max() <= ATOL and (err <= ATOL + RTOL * np.abs(ref)).all(), err.max()
-    for chunks in (1, 2, 4, 16):
-        got = fa.forward_shard_gather(q, k, v, heads, chunks=chunks)
-        assert got.shape == plain.shape
-        assert torch.equal(got, plain), (heads, N, d, chunks, (got.float() - plain.float()).abs().max().item())
+    for exchange in ("p2p", "all_gather"):       # one rank: no peers to exchange with / RCCL all-gather of one
+        for chunks in (1, 2, 4, 16):
+            got = fa.forward_shard_gather(q, k, v, heads, chunks=chunks, exchange=exchange)
+            assert got.shape == plain.shape
+            assert torch.equal(got, plain), (heads, N, d, exchange, chunks,
+                                             (got.float() - plain.float()).abs().max().item())
     # preallocated output, no host sync inside the call
     buf = torch.empty_like(plain)
     got = fa.forward_shard_gather(q, k, v, heads, chunks=3, out=buf, sync=False)
