@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--gather-chunks", type=int, default=0,
                     help="also time the forward with the optional all-gather of O overlapped in this many "
                          "head chunks (reported beside the metric, never part of `value`)")
+    ap.add_argument("--gather-exchange", default="p2p", choices=["p2p", "all_gather"])
     args = ap.parse_args()
 
     import torch
@@ -178,17 +179,20 @@ def main():
         qs, ks, vs = (x.view(B * H, N, d) for x in (q, k, v))
         full = torch.empty((world * B * H, N, d), dtype=q.dtype, device=dev)
         for _ in range(max(2, args.warmup)):
-            fa.forward_shard_gather(qs, ks, vs, world * B * H, kt, chunks=args.gather_chunks, out=full, sync=False)
+            fa.forward_shard_gather(qs, ks, vs, world * B * H, kt, chunks=args.gather_chunks, out=full, sync=False,
+                                    exchange=args.gather_exchange)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            fa.forward_shard_gather(qs, ks, vs, world * B * H, kt, chunks=args.gather_chunks, out=full, sync=False)
+            fa.forward_shard_gather(qs, ks, vs, world * B * H, kt, chunks=args.gather_chunks, out=full, sync=False,
+                                    exchange=args.gather_exchange)
         barrier()
         tg = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         same = bool(torch.equal(full[rank * B * H:(rank + 1) * B * H], o.view(B * H, N, d)))
         gather = {
             "chunks": args.gather_chunks,
+            "exchange": args.gather_exchange,
             "ms_per_step": round(float(tg.item()) / args.steps * 1e3, 4),
             "gathered_bytes_per_gpu": (world - 1) * B * H * N * d * 2,
             "own_slab_identical_to_plain_forward": same,
