@@ -1103,11 +1103,15 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     {
       drain_o(o);
       constexpr uint32_t vb = (uint32_t)(3 * kTileBytes + kBlkBytes);
+      // all V^T fragments of the block first (the score registers are free by now): one LDS round trip
+      // instead of one per fragment
+      f16x8 vf[kDv16];
+#pragma unroll
+      for (int b = 0; b < kDv16; ++b) vf[b] = read_v<D>(vb, la, b);
 #pragma unroll
       for (int b = 0; b < kDv16; ++b) {
-        const f16x8 vf = read_v<D>(vb, la, b);
 #pragma unroll
-        for (int q = 0; q < kQ16; ++q) mfma_o<true, EK>(o[q][b], vf, pB[q]);
+        for (int q = 0; q < kQ16; ++q) mfma_o<true, EK>(o[q][b], vf[b], pB[q]);
       }
       drain_o(o);
       drain_lsum(lsum);
