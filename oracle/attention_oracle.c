@@ -4,11 +4,13 @@
  * this file.  The shipped product (libflash_hip.so and everything above it) never does.
  *
  * Parity status: PINNED.  The functions here are checked (tests/test_oracle.py) against golden
- * vectors in tests/golden/ that were produced by running the reference's own oracle expression
- * `softmax(q @ k^T * 1/sqrt(d)) @ v` with the libtorch CPU operators the reference calls
- * (reference main.cpp:12-17 `manual_attn`, benchmarks/bench.py:39-43), on the reference's test
- * inputs (torch::manual_seed(0), randn q, k, v in that order, main.cpp:24-34) and test shapes
- * (main.cpp:157-193).  The generating script is tests/golden/make_golden.py.
+ * vectors in tests/golden/ that are outputs of the reference's own oracle function: the generating
+ * script tests/golden/make_golden.py takes the definition of `manual_attn` out of the reference's
+ * benchmarks/bench.py (lines 39-43; the same expression as main.cpp:12-17) and executes that text,
+ * unmodified, against the local torch on the reference's test inputs (manual_seed(0), randn q, k, v
+ * in that order, main.cpp:24-34) and test shapes (main.cpp:157-193).  `make_golden.py --check`
+ * (run by tests/test_oracle.py wherever the reference tree is present) regenerates the vectors and
+ * requires the committed files to be bit-identical.
  *
  * Two algorithms:
  *   oracle_attn_naive      — the reference's oracle: S = Q K^T * scale, P = softmax(S), O = P V,
@@ -172,12 +174,17 @@ int oracle_attn_naive(const float* q, const float* k, const float* v, float* o, 
  *                     reference does (:220-233); nonzero: keep O unnormalised and divide once at
  *                     the end (what the MI355X kernel does)
  *   m_out, l_out      optional [B, H, N] final row max (of scaled scores) and row sum
+ *   q_prescale_f16    (oracle_attn_tiled_q16 only) nonzero: model the one discretionary rounding of
+ *                     the MI355X kernel: the query row is multiplied by scale*log2(e) and rounded to
+ *                     fp16 once, scores are the plain dot products of that row, probabilities are
+ *                     exp2(score - max).  m_out is then reported in the same log2 domain.
  * Inputs are used as given; callers that model fp16 operands pass fp16-rounded values.
  */
-int oracle_attn_tiled(const float* q, const float* k, const float* v, float* o, int64_t B, int64_t H, int64_t N,
-                      int64_t d, float scale, int Br, int Bc, int p_f16, int defer_norm, float* m_out,
-                      float* l_out) {
+static int attn_tiled_impl(const float* q, const float* k, const float* v, float* o, int64_t B, int64_t H, int64_t N,
+                           int64_t d, float scale, int Br, int Bc, int p_f16, int defer_norm, int q_prescale_f16,
+                           float* m_out, float* l_out) {
   if (Br <= 0 || Bc <= 0) return -2;
+  const float kLog2e = 1.44269504088896340736f;
   const int64_t heads = B * H;
   const int64_t nqt = (N + Br - 1) / Br;
   int failed = 0;
@@ -187,14 +194,15 @@ int oracle_attn_tiled(const float* q, const float* k, const float* v, float* o, 
     float* Oacc = (float*)malloc((size_t)Br * d * sizeof(float));
     float* mprev = (float*)malloc((size_t)Br * sizeof(float));
     float* lprev = (float*)malloc((size_t)Br * sizeof(float));
-    if (!S || !Oacc || !mprev || !lprev) {
+    float* qrow = (float*)malloc((size_t)(d > 0 ? d : 1) * sizeof(float));
+    if (!S || !Oacc || !mprev || !lprev || !qrow) {
 #pragma omp atomic write
       failed = 1;
     }
 #pragma omp for collapse(2) schedule(dynamic, 1)
     for (int64_t bh = 0; bh < heads; ++bh) {
       for (int64_t it = 0; it < nqt; ++it) {
-        if (!S || !Oacc || !mprev || !lprev) continue;
+        if (!S || !Oacc || !mprev || !lprev || !qrow) continue;
         const float* qh = q + bh * N * d;
         const float* kh = k + bh * N * d;
         const float* vh = v + bh * N * d;
@@ -209,28 +217,32 @@ int oracle_attn_tiled(const float* q, const float* k, const float* v, float* o, 
           const int Bcc = (int)((N - jStart) < Bc ? (N - jStart) : Bc); /* :102 */
           for (int ii = 0; ii < Brc; ++ii) {
             const float* qi = qh + (iStart + ii) * d;
+            if (q_prescale_f16) {
+              for (int64_t x = 0; x < d; ++x) qrow[x] = oracle_round_f16(qi[x] * (scale * kLog2e));
+              qi = qrow;
+            }
             /* S = Q K^T * scale, row max (:148-168) */
             float mcur = -INFINITY;
             for (int jj = 0; jj < Bcc; ++jj) {
               const float* kj = kh + (jStart + jj) * d;
               float dot = 0.f;
               for (int64_t x = 0; x < d; ++x) dot += qi[x] * kj[x];
-              dot *= scale;
+              if (!q_prescale_f16) dot *= scale;
               S[ii * Bc + jj] = dot;
               mcur = dot > mcur ? dot : mcur;
             }
             /* P = exp(S - m), row sum (:173-188) */
             float lcur = 0.f;
             for (int jj = 0; jj < Bcc; ++jj) {
-              float pij = expf(S[ii * Bc + jj] - mcur);
+              float pij = q_prescale_f16 ? exp2f(S[ii * Bc + jj] - mcur) : expf(S[ii * Bc + jj] - mcur);
               lcur += pij;
               if (p_f16) pij = oracle_round_f16(pij);
               S[ii * Bc + jj] = pij;
             }
             /* (m, l) recurrence (:253-263) */
             const float mnew = mprev[ii] > mcur ? mprev[ii] : mcur;
-            const float a_prev = expf(mprev[ii] - mnew);
-            const float a_cur = expf(mcur - mnew);
+            const float a_prev = q_prescale_f16 ? exp2f(mprev[ii] - mnew) : expf(mprev[ii] - mnew);
+            const float a_cur = q_prescale_f16 ? exp2f(mcur - mnew) : expf(mcur - mnew);
             const float lnew = a_prev * lprev[ii] + a_cur * lcur;
             /* O update (:194-233): PV for this tile, then rescale */
             for (int64_t x = 0; x < d; ++x) {
@@ -259,6 +271,19 @@ int oracle_attn_tiled(const float* q, const float* k, const float* v, float* o, 
     free(Oacc);
     free(mprev);
     free(lprev);
+    free(qrow);
   }
   return failed ? -1 : 0;
+}
+
+int oracle_attn_tiled(const float* q, const float* k, const float* v, float* o, int64_t B, int64_t H, int64_t N,
+                      int64_t d, float scale, int Br, int Bc, int p_f16, int defer_norm, float* m_out,
+                      float* l_out) {
+  return attn_tiled_impl(q, k, v, o, B, H, N, d, scale, Br, Bc, p_f16, defer_norm, 0, m_out, l_out);
+}
+
+int oracle_attn_tiled_q16(const float* q, const float* k, const float* v, float* o, int64_t B, int64_t H, int64_t N,
+                          int64_t d, float scale, int Br, int Bc, int p_f16, int defer_norm, int q_prescale_f16,
+                          float* m_out, float* l_out) {
+  return attn_tiled_impl(q, k, v, o, B, H, N, d, scale, Br, Bc, p_f16, defer_norm, q_prescale_f16, m_out, l_out);
 }

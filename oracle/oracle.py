@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY: imported by tests/, by ``__graft_entry__.smoke()`` and
 ``cpu_baseline`` leg of ``bench.py``.  Nothing under ``flash-attention_amd/`` imports it.
 
 Parity status: pinned — see the header of attention_oracle.c and tests/test_oracle.py (golden
-vectors produced with the libtorch operators the reference's own oracle calls, reference
-main.cpp:12-17).
+vectors are outputs of the reference's own ``manual_attn`` definition, benchmarks/bench.py:39-43,
+executed unmodified by tests/golden/make_golden.py; ``--check`` requires them bit-identical).
 """
 from __future__ import annotations
 
@@ -43,6 +43,9 @@ def lib() -> ctypes.CDLL:
         L.oracle_attn_tiled.argtypes = [fp, fp, fp, fp, i64, i64, i64, i64, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
         L.oracle_attn_tiled.restype = ctypes.c_int
+        L.oracle_attn_tiled_q16.argtypes = [fp, fp, fp, fp, i64, i64, i64, i64, ctypes.c_float,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.oracle_attn_tiled_q16.restype = ctypes.c_int
         L.oracle_round_f16_array.argtypes = [fp, fp, i64]
         L.oracle_round_f16_array.restype = None
         L.oracle_num_threads.argtypes = []
@@ -94,8 +97,10 @@ def attn_naive(q, k, v, scale: float | None = None) -> np.ndarray:
 
 
 def attn_tiled(q, k, v, scale: float | None = None, Br: int = 128, Bc: int = 64, p_f16: bool = False,
-               defer_norm: bool = False, return_ml: bool = False):
-    """The hot kernel's tile loop (reference flash/kernel_mma_qreg.cuh:100-266) on the CPU."""
+               defer_norm: bool = False, return_ml: bool = False, q_prescale_f16: bool = False):
+    """The hot kernel's tile loop (reference flash/kernel_mma_qreg.cuh:100-266) on the CPU.
+    ``q_prescale_f16`` models the MI355X kernel's rounding of Q * scale * log2(e) to fp16 (exp2 domain;
+    the returned m is then in log2 units)."""
     q, k, v = _f32(q), _f32(k), _f32(v)
     B, H, N, d = q.shape
     if scale is None:
@@ -103,8 +108,8 @@ def attn_tiled(q, k, v, scale: float | None = None, Br: int = 128, Bc: int = 64,
     o = np.empty_like(q)
     m = np.empty((B, H, N), dtype=np.float32)
     l = np.empty((B, H, N), dtype=np.float32)
-    rc = lib().oracle_attn_tiled(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, d, float(scale), Br, Bc,
-                                 int(p_f16), int(defer_norm), _ptr(m), _ptr(l))
+    rc = lib().oracle_attn_tiled_q16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), B, H, N, d, float(scale), Br, Bc,
+                                     int(p_f16), int(defer_norm), int(q_prescale_f16), _ptr(m), _ptr(l))
     if rc != 0:
         raise RuntimeError(f"oracle_attn_tiled failed rc={rc}")
     return (o, m, l) if return_ml else o

@@ -1,28 +1,44 @@
-"""Generate the golden vectors in tests/golden/*.npz.
+"""Generate (or check) the golden vectors in tests/golden/*.npz by running the reference's own oracle.
 
-The reference has no golden files; its tests recompute `manual_attn` with libtorch on every run
-(reference main.cpp:12-17, 67-79).  This script runs that same expression with the local torch CPU
-operators (matmul, softmax, matmul) on the reference's test inputs — torch.manual_seed(0), then
-randn for q, k, v in that order (main.cpp:24-34) — for the reference runner's five shapes
-(main.cpp:157-193) and the tiny plumbing configuration (2, 4, 256, 64), and stores
+The reference has no golden files; its tests recompute `manual_attn` with torch on every run
+(reference main.cpp:12-17, 67-79; benchmarks/bench.py:39-43).  This script does not restate that
+function: it reads /root/reference/benchmarks/bench.py as text, takes the `manual_attn` function
+definition out of its syntax tree (the module cannot be imported whole: line 14 loads a library that
+is never built here and line 34 needs a GPU), compiles exactly that definition and executes it with
+the names it uses bound to the real local modules (`math`, `torch`, `torch.nn.functional` as `F`,
+bound as the reference's lines 1-3 bind them).  Inputs are the reference's test inputs —
+torch.manual_seed(0), then randn for q, k, v in that order (main.cpp:24-34) — for the reference
+runner's five shapes (main.cpp:157-193) and the tiny plumbing configuration (2, 4, 256, 64).
 
+Stored per fixture
   q32/k32/v32   the fp32 inputs as the reference generates them
   q/k/v         the same rounded to fp16 (what the MI355X kernel consumes)
-  o_f32         manual_attn(q32, k32, v32)            fp32 oracle on the reference's own inputs
-  o             manual_attn(q.float(), k.float(), v.float())   fp32 oracle on the fp16-rounded inputs
-  m, l          row max of the scaled scores and row sum of exp(score - m) for `o`
+  o_f32         reference manual_attn(q32, k32, v32)                    on the reference's own inputs
+  o             reference manual_attn(q.float(), k.float(), v.float())  on the fp16-rounded inputs
+  m, l          row max of the scaled scores and row sum of exp(score - m) for `o` (torch ops; these
+                two pin the online-softmax state of the tiled restatement, they are not produced by
+                reference code)
+  ref_lines     first and last source line of the executed definition in the reference file
 
 For the two multi-head shapes only a few (batch, head) slices are kept (heads are independent), so
-every fixture stays small.  Run from the repository root:  python tests/golden/make_golden.py
+every fixture stays small.  Nothing of the reference's text is written into a fixture or this
+repository; only numbers are.  Needs /root/reference, i.e. the build container:
+
+    python tests/golden/make_golden.py           # rewrite the fixtures
+    python tests/golden/make_golden.py --check   # regenerate in memory, require bit-identical arrays
 """
+import argparse
+import ast
 import math
 import os
+import sys
 
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE_BENCH = "/root/reference/benchmarks/bench.py"
 
 # (B, H, N, d), heads kept
 CASES = [
@@ -35,14 +51,30 @@ CASES = [
 ]
 
 
-def manual_attn(q, k, v):
-    att = q @ k.transpose(-2, -1) * (1.0 / math.sqrt(k.size(-1)))
-    att = F.softmax(att, dim=-1)
-    return att @ v
+def reference_available():
+    return os.path.isfile(REFERENCE_BENCH)
 
 
-def main():
+def load_reference_manual_attn(path=REFERENCE_BENCH):
+    """Return (function, (first_line, last_line)): the reference's `manual_attn`, compiled from the
+    reference file's own text and nothing else."""
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "manual_attn"]
+    if len(defs) != 1:
+        raise RuntimeError(f"expected one top-level manual_attn in {path}, found {len(defs)}")
+    node = defs[0]
+    module = ast.Module(body=[node], type_ignores=[])
+    env = {"math": math, "torch": torch, "F": F}
+    exec(compile(module, path, "exec"), env)
+    return env["manual_attn"], (node.lineno, node.end_lineno)
+
+
+def generate():
+    """{file name: {array name: ndarray}} for every case."""
+    manual_attn, lines = load_reference_manual_attn()
     torch.set_num_threads(1)
+    out = {}
     for (B, H, N, d), keep in CASES:
         torch.manual_seed(0)
         q32 = torch.randn(B, H, N, d)
@@ -61,16 +93,54 @@ def main():
         def pick(t):
             return np.stack([t[b, h].numpy() for (b, h) in keep])[None]  # [1, n_kept, ...]
 
-        out = dict(
+        out[f"attn_B{B}_H{H}_N{N}_d{d}.npz"] = dict(
             shape=np.array([B, H, N, d], dtype=np.int64),
             heads=np.array(keep, dtype=np.int64),
             q32=pick(q32), k32=pick(k32), v32=pick(v32),
             q=pick(q16), k=pick(k16), v=pick(v16),
             o_f32=pick(o_f32), o=pick(o), m=pick(m), l=pick(l),
+            ref_lines=np.array(lines, dtype=np.int64),
         )
-        path = os.path.join(HERE, f"attn_B{B}_H{H}_N{N}_d{d}.npz")
-        np.savez_compressed(path, **out)
-        print(path, os.path.getsize(path), "bytes; torch", torch.__version__)
+    return out
+
+
+def check():
+    """Regenerate every fixture in memory and compare with the committed files bit for bit.
+    Returns a list of differences (empty = identical)."""
+    bad = []
+    for name, arrays in generate().items():
+        path = os.path.join(HERE, name)
+        if not os.path.exists(path):
+            bad.append(f"{name}: missing")
+            continue
+        with np.load(path) as have:
+            if sorted(have.files) != sorted(arrays):
+                bad.append(f"{name}: arrays {sorted(have.files)} != {sorted(arrays)}")
+                continue
+            for key, want in arrays.items():
+                got = have[key]
+                if got.dtype != want.dtype or got.shape != want.shape or got.tobytes() != want.tobytes():
+                    bad.append(f"{name}[{key}] differs")
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    if not reference_available():
+        sys.exit(f"{REFERENCE_BENCH} not found: fixtures are generated in the build container only")
+    if args.check:
+        bad = check()
+        for b in bad:
+            print("MISMATCH", b)
+        print("golden fixtures:", "bit-identical to the reference's manual_attn run here" if not bad else "DIFFER")
+        sys.exit(1 if bad else 0)
+    for name, arrays in generate().items():
+        path = os.path.join(HERE, name)
+        np.savez_compressed(path, **arrays)
+        print(path, os.path.getsize(path), "bytes; torch", torch.__version__,
+              "reference lines", tuple(arrays["ref_lines"]))
 
 
 if __name__ == "__main__":
