@@ -22,6 +22,8 @@ import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -88,6 +90,36 @@ def measured_traffic(workload):
         return None
 
 
+def launch_ranks(n_ranks):
+    """`python bench.py --gpus N` started as one plain process: start N fresh rank processes of this
+    script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, a free rendezvous port),
+    relay rank 0's JSON line and return non-zero if any rank fails.  This parent never imports torch
+    and never touches a GPU; the ranks are children, not replacements of this process."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    deadline = time.time() + 120
+    for pr in procs[1:]:
+        try:
+            pr.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            pr.kill()          # this exact child; rank 0 is gone, so it can only be stuck in a collective
+            pr.wait()
+        rc = rc or pr.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +131,8 @@ def main():
                     help="tensor type; the metric is defined on fp16, bf16 runs the same kernels with bfloat16 "
                          "matrix instructions (parity is then checked against the bf16 bar of 1.6e-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures of the headline run (sustained >= 1 s rate, batch-4 rate)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL; gloo lets several ranks rehearse the "
                          "multi-rank path on a box with fewer GPUs than ranks)")
@@ -107,6 +141,10 @@ def main():
                          "head chunks (reported beside the metric, never part of `value`)")
     ap.add_argument("--gather-exchange", default="p2p", choices=["p2p", "all_gather"])
     args = ap.parse_args()
+
+    # N > 1 without a launcher around us: become the launcher, before anything GPU-related is imported
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -117,10 +155,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world         # under a launcher the launcher's world size is the number of ranks
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU path for the attention kernel")
     n_dev = torch.cuda.device_count()
@@ -130,7 +165,10 @@ def main():
     torch.cuda.set_device(dev)
     if world > 1 or args.gather_chunks > 0:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:   # single process with --gather-chunks: any free port
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
@@ -198,7 +236,37 @@ def main():
             "own_slab_identical_to_plain_forward": same,
         }
 
+    # secondary figures, single-GPU headline runs only, outside the timed region of `value`:
+    #  - the same launch repeated for at least a second (clocks under sustained matrix load settle
+    #    below what a 0.1 s burst sees),
+    #  - the same head shape at batch 4 (the configuration of the reference's own study).
+    secondary = None
+    if world == 1 and args.workload == "headline" and not args.no_secondary:
+        def timed_launches(tq, tk, tv, to, n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fa.forward(tq, tk, tv, kt, out=to, sync=False)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / n
+
+        n_sus = max(args.steps, int(1.2e3 / max(kernel_ms, 1e-3)) + 1)
+        ms_sus = timed_launches(q, k, v, o, n_sus)
+        b4 = WORKLOADS["gpt3_4k_b4"]
+        ms_b4 = timed_launches(q[:4], k[:4], v[:4], o[:4], max(args.steps, 20))
+        secondary = {
+            "sustained": {"launches": n_sus, "kernel_ms": round(ms_sus, 4),
+                          "tflops": round(attention_flops(*shape) / ms_sus / 1e9, 2),
+                          "frac": round(attention_flops(*shape) / ms_sus / 1e9 / PEAK_TFLOPS_FP16_DENSE, 4)},
+            "gpt3_4k_b4": {"shape": list(b4), "kernel_ms": round(ms_b4, 4),
+                           "tflops": round(attention_flops(*b4) / ms_b4 / 1e9, 2),
+                           "frac": round(attention_flops(*b4) / ms_b4 / 1e9 / PEAK_TFLOPS_FP16_DENSE, 4)},
+        }
+
     if rank == 0:
+        info = fa.launch_info(B, H, N, d, kt, fa.ENTRY_BF16 if args.dtype == "bf16" else fa.ENTRY_F16)
+        pers = info.persistent    # what the library routes this shape to right now (environment included)
         flops = attention_flops(*shape)
         value = world * flops * args.steps / elapsed / 1e12
         achieved = flops / (kernel_ms * 1e-3) / 1e12
@@ -232,11 +300,11 @@ def main():
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
                 "traffic": measured_traffic(args.workload),
                 "kernel": "flash_hip::m16::attn_fwd_kernel_m16{}<{}, {}>".format(
-                    "p" if N % 256 == 0 else "", 128 if d > 64 else 64,
+                    "p" if pers else "", 128 if d > 64 else 64,
                     "_Float16" if args.dtype == "fp16" else "flash_hip::m16::bf16_out"),
                 # the same kernel as rocprofv3's CSV output names it (mangled)
                 "kernel_symbol": "_ZN9flash_hip3m16{}attn_fwd_kernel_m16{}ILi{}E{}EEvNS_9FwdParamsE".format(
-                    20 if N % 256 == 0 else 19, "p" if N % 256 == 0 else "", 128 if d > 64 else 64,
+                    20 if pers else 19, "p" if pers else "", 128 if d > 64 else 64,
                     "DF16_" if args.dtype == "fp16" else "NS0_8bf16_outE"),
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops,
@@ -256,6 +324,8 @@ def main():
             line["parity"] = {"max_abs_vs_cpu_oracle": err, "bar": bar, "ok": bool(err <= bar)}
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(orc, shape)
+        if secondary is not None:
+            line["secondary"] = secondary
         if gather is not None:
             gather["exposed_ms_per_step"] = round(gather["ms_per_step"] - line["ms_per_step"], 4)
             line["forward_plus_overlapped_gather"] = gather

@@ -20,6 +20,14 @@ Rows
   mma_qreg_async_fp32  the same op on fp32 tensors (conversion pass into scratch + fp16 kernel, fp32 out)
   mma_qreg_async_bf16  the same op on bfloat16 tensors
 
+Two timing columns per row: `ms` = average of back-to-back calls between two HIP events, and
+`profiler_ms` = the reference's own method (benchmarks/bench.py:58-66): one call under
+torch.autograd.profiler, sum of self_device_time_total over key_averages() — here after warm-up.
+
+Every sequence length is also a parity check: the last head of the native output is compared with the
+CPU oracle (fp32 softmax(QK^T/sqrt(d))V on the same fp16 inputs) and the script exits non-zero if
+max-abs exceeds 2e-3 or any element leaves 2e-3 + 1e-2*|ref|.
+
   python benchmarks/sweep.py [--out profiles/sweep.json] [--max-n 16384] [--reps 10]
 """
 from __future__ import annotations
@@ -86,9 +94,25 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / args.reps
 
+    def profiler_ms(fn, q, k, v):
+        """The reference's profile_kernel (benchmarks/bench.py:58-66): sum of self device time of one call."""
+        import torch.autograd.profiler as profiler
+
+        with profiler.profile(use_device="cuda") as prof:
+            fn(q, k, v)
+            torch.cuda.synchronize(dev)
+        return sum(item.self_device_time_total for item in prof.key_averages()) / 1e3
+
+    from oracle import oracle as orc
+    import numpy as np
+
+    orc.build()
     seqs = [n for n in (512, 1024, 2048, 4096, 8192, 16384) if n <= args.max_n]
     data = {"Sequence Length": seqs}
     tflops = {}
+    prof_data = {}
+    parity = []
+    failed = False
     gen = torch.Generator(device=dev).manual_seed(0)
     for N in seqs:
         q, k, v = (torch.randn(B, H, N, d, device=dev, generator=gen).half() for _ in range(3))
@@ -100,30 +124,48 @@ def main():
         for name, fn in rows:
             try:
                 ms = time_ms(fn, q, k, v)
+                pms = profiler_ms(fn, q, k, v)
                 if name == "torch_flash_v2":
                     ref = fn(q, k, v)
             except torch.OutOfMemoryError as e:   # the N x N score matrix of manual_attn at long N
-                ms = 0.0
+                ms = pms = 0.0
                 print("  out of memory:", str(e).split("\n")[0])
                 torch.cuda.empty_cache()
             data.setdefault(name, []).append(round(ms, 4))
+            prof_data.setdefault(name, []).append(round(pms, 4))
             tflops.setdefault(name, []).append(round(flops / (ms * 1e-3) / 1e12, 1) if ms else 0.0)
-            print(f"  {name}: {ms:.3f} ms  {tflops[name][-1]} TFLOP/s", flush=True)
+            print(f"  {name}: {ms:.3f} ms  {tflops[name][-1]} TFLOP/s   (profiler sum {pms:.3f} ms)", flush=True)
+        o_nat = pyflash.mma_qreg_async(q, k, v)
         if ref is not None:
-            err = float((pyflash.mma_qreg_async(q, k, v).float() - ref.float()).abs().max())
+            err = float((o_nat.float() - ref.float()).abs().max())
             print(f"  max |native - torch SDPA| = {err:.2e}")
+        # parity gate: last head (the one at the highest byte offset) against the CPU oracle
+        hq, hk, hv = (x[B - 1:B, H - 1:H].float().cpu().numpy() for x in (q, k, v))
+        want = orc.attn_naive(hq, hk, hv)[0, 0]
+        got = o_nat[B - 1, H - 1].float().cpu().numpy()
+        diff = np.abs(got - want)
+        ok = bool(diff.max() <= 2e-3 and (diff <= 2e-3 + 1e-2 * np.abs(want)).all())
+        parity.append({"N": N, "head": [B - 1, H - 1], "max_abs_vs_cpu_oracle": float(diff.max()), "ok": ok})
+        print(f"  max |native - CPU oracle| (head {B - 1},{H - 1}) = {diff.max():.2e}  {'ok' if ok else 'FAIL'}", flush=True)
+        failed = failed or not ok
+        del o_nat
         del q, k, v, q32, k32, v32, qb, kb, vb
         torch.cuda.empty_cache()
 
     print()
     print(data)
     result = {"shape": {"B": B, "H": H, "d": d, "dtype": "fp16"}, "ms": data, "tflops": tflops,
-              "method": f"average of {args.reps} back-to-back calls between two HIP events after 3 warm-up calls, one MI355X",
+              "profiler_ms": prof_data, "parity": parity,
+              "method": f"ms: average of {args.reps} back-to-back calls between two HIP events after 3 warm-up calls; "
+                        "profiler_ms: sum of self_device_time_total of one warmed-up call under torch.autograd.profiler "
+                        "(the reference's method); one MI355X",
               "torch": torch.__version__}
     if args.out:
         with open(args.out, "w") as f:
             json.dump(result, f, indent=1)
         print("wrote", args.out)
+    if failed:
+        raise SystemExit("parity against the CPU oracle failed at one or more sequence lengths")
 
 
 if __name__ == "__main__":

@@ -49,7 +49,7 @@ _OK, _EINVAL, _EDIM, _ERUNTIME, _ELDS = 0, -1, -2, -3, -4
 class _LaunchInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in (
         "tile_kv", "tile_q", "tile_d", "lds_bytes", "block_x", "block_y",
-        "grid_x", "grid_y", "grid_z", "staging", "aligned_rows")]
+        "grid_x", "grid_y", "grid_z", "staging", "aligned_rows", "persistent")]
 
 
 @dataclass(frozen=True)
@@ -62,11 +62,13 @@ class LaunchInfo:
     grid_dim: Tuple[int, int, int]    # (B, H, ceil(N/Br))         == gridDim()
     staging: int
     aligned_rows: bool
+    persistent: bool = False          # items walked by one persistent workgroup per compute unit
 
 
 # every symbol include/flash_hip.h declares
 ABI_SYMBOLS = (
     "flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_ws", "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
+    "flash_fwd_query_entry",
     "flash_kernel_type_name",
     "flash_hip_last_error", "flash_hip_version",
 )
@@ -99,6 +101,8 @@ def lib() -> ctypes.CDLL:
     L.flash_fwd_f32_workspace_bytes.restype = i64
     L.flash_fwd_query.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.POINTER(_LaunchInfo)]
     L.flash_fwd_query.restype = ctypes.c_int
+    L.flash_fwd_query_entry.argtypes = [i64, i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_LaunchInfo)]
+    L.flash_fwd_query_entry.restype = ctypes.c_int
     L.flash_kernel_type_name.argtypes = [ctypes.c_int]
     L.flash_kernel_type_name.restype = ctypes.c_char_p
     L.flash_hip_last_error.argtypes = []
@@ -125,16 +129,21 @@ def to_string(kernel_type) -> str:
     return name.decode()
 
 
-def launch_info(B: int, H: int, N: int, d: int, kernel_type=KernelType.mma_qreg_async) -> LaunchInfo:
-    """Counterpart of ``KernelParametersFactory::create`` (flash/KernelParameters.hpp:383-422)."""
+ENTRY_F16, ENTRY_BF16, ENTRY_F32 = 0, 1, 2  # flash_hip_entry (include/flash_hip.h)
+
+
+def launch_info(B: int, H: int, N: int, d: int, kernel_type=KernelType.mma_qreg_async, entry: int = ENTRY_F16) -> LaunchInfo:
+    """Counterpart of ``KernelParametersFactory::create`` (flash/KernelParameters.hpp:383-422).
+    ``entry`` names the entry point described: fp16 (default; also fp32 with scratch), bf16, or fp32
+    without scratch (element staging)."""
     info = _LaunchInfo()
-    rc = lib().flash_fwd_query(B, H, N, d, int(kernel_type), ctypes.byref(info))
+    rc = lib().flash_fwd_query_entry(B, H, N, d, int(kernel_type), int(entry), ctypes.byref(info))
     if rc != _OK:
         _raise(rc)
     return LaunchInfo(
         tile_size=(info.tile_kv, info.tile_q, info.tile_d), sram_size=info.lds_bytes,
         block_dim=(info.block_x, info.block_y), grid_dim=(info.grid_x, info.grid_y, info.grid_z),
-        staging=info.staging, aligned_rows=bool(info.aligned_rows))
+        staging=info.staging, aligned_rows=bool(info.aligned_rows), persistent=bool(info.persistent))
 
 
 def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: bool = True):
@@ -329,7 +338,7 @@ def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mm
 
 
 __all__ = [
-    "KernelType", "LaunchInfo", "ABI_SYMBOLS", "lib", "to_string", "launch_info", "forward",
+    "KernelType", "LaunchInfo", "ABI_SYMBOLS", "ENTRY_F16", "ENTRY_BF16", "ENTRY_F32", "lib", "to_string", "launch_info", "forward",
     "load_pyflash", "shard_heads", "forward_shard", "gather_output", "head_chunks",
     "forward_shard_gather",
     "LIB_PATH", "PYFLASH_PATH", "RUNNER_PATH", "REPO_ROOT",

@@ -104,12 +104,15 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
   // Above the 64 KiB default a kernel must opt in to its dynamic LDS size (the reference does the
   // same above 48 KiB, launch.cu:134-148).
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  if (dev < 16 && !attr_done[dev]) {
+  hipError_t de = hipGetDevice(&dev);
+  if (de != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "hipGetDevice failed: %s", hipGetErrorString(de));
+  // the per-device cache covers ordinals 0..15; beyond that (partitioned nodes expose up to 64
+  // devices) the attribute is simply set on every call
+  if (dev < 0 || dev >= 16 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
       return fail(FLASH_HIP_ERR_LDS, "Failed to set dynamic shared memory size %u: %s", lds, hipGetErrorString(e));
-    attr_done[dev] = true;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
   }
 #if defined(FLASH_PHASE_STAMPS)
   // diagnostic build: collect and print the per-wave phase stamps of this launch (synchronises)
@@ -208,6 +211,13 @@ int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t s
   return plan.tile_d == 64 ? launch_m16<64, TO>(prm, plan.lds, stream) : launch_m16<128, TO>(prm, plan.lds, stream);
 }
 
+// The fast kernels move 16 bytes per lane (128-bit buffer loads and stores, global->LDS DMA): a tensor
+// whose base is not 16-byte aligned (a view that starts inside an allocation) goes to the
+// element-staging kernel instead, which only needs element alignment.
+bool aligned16(const void* a, const void* b, const void* c, const void* d) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
+}
+
 // Bytes of one fp16 copy of a tensor in the workspace of flash_fwd_f32_ws (256-byte granules)
 int64_t ws_tensor_bytes(int64_t B, int64_t H, int64_t N, int64_t d) { return (B * H * N * d * 2 + 255) / 256 * 256; }
 
@@ -221,7 +231,7 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan);
   hipStream_t stream = (hipStream_t)hip_stream;
   if constexpr (sizeof(T) == 2) {
-    if (plan.fast) {
+    if (plan.fast && aligned16(q, k, v, o)) {
 #if defined(FLASH_MFMA32)  // comparison builds: the 32x32x16 kernel on the fast path as well
       return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
 #else
@@ -255,6 +265,8 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
     return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
                 (long long)d);
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
+  if (!aligned16(q, k, v, o))
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "bfloat16 tensors must be 16-byte aligned");
   const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan);
   return launch_fast<m16::bf16_out>(prm, plan, N, (hipStream_t)hip_stream);
 }
@@ -270,7 +282,9 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64
   Plan plan;
   int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
   if (rc != FLASH_HIP_OK) return rc;
-  if (!plan.fast || !workspace)  // rows without 16-byte chunks, or no workspace: convert while staging
+  // rows without 16-byte chunks, no workspace, or tensors that do not start on a 16-byte boundary:
+  // convert while staging
+  if (!plan.fast || !workspace || !aligned16(q, k, v, o))
     return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
   const int64_t each = ws_tensor_bytes(B, H, N, d);
@@ -297,10 +311,21 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64
 }
 
 int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, flash_launch_info* out) {
+  return flash_fwd_query_entry(B, H, N, d, kernel_type, FLASH_ENTRY_F16, out);
+}
+
+int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, int entry,
+                          flash_launch_info* out) {
   if (!out) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null flash_launch_info");
+  if (entry < FLASH_ENTRY_F16 || entry > FLASH_ENTRY_F32)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "unknown entry point selector %d", entry);
   Plan plan;
-  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
+  // flash_fwd_f32 (no workspace) stages fp32 elements through registers whatever the head dim
+  int rc = make_plan(B, H, N, d, kernel_type, entry != FLASH_ENTRY_F32, &plan);
   if (rc != FLASH_HIP_OK) return rc;
+  if (entry == FLASH_ENTRY_BF16 && !plan.fast)
+    return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
+                (long long)d);
   out->tile_kv = kBc;
   out->tile_q = kBr;
   out->tile_d = (uint32_t)plan.tile_d;
@@ -315,6 +340,7 @@ int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type,
   out->grid_z = plan.nqt;
   out->staging = (uint32_t)plan.staging;
   out->aligned_rows = (d % 8 == 0) ? 1u : 0u;
+  out->persistent = persistent ? 1u : 0u;
   return FLASH_HIP_OK;
 }
 
@@ -325,6 +351,6 @@ const char* flash_kernel_type_name(int kernel_type) {
 
 const char* flash_hip_last_error(void) { return g_err; }
 
-int flash_hip_version(void) { return 100; }
+int flash_hip_version(void) { return 200; }
 
 }  // extern "C"

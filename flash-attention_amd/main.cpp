@@ -121,9 +121,13 @@ double time_ms(const std::function<void()>& fn) {
   return std::chrono::duration<double, std::milli>(t1 - t0).count();
 }
 
-void report(const std::string& name, double ms, const Shape& s, int64_t heads_total) {
+void report(const std::string& name, double ms, const Shape& s, int64_t heads_total, int gpus = 1) {
   const double flops = 4.0 * static_cast<double>(heads_total) * s.seq * s.seq * s.dim;
-  std::cout << "Benchmark '" << name << "' took " << ms << " [ms]  (" << flops / ms * 1e-9 << " TFLOP/s)" << std::endl;
+  // fraction of the dense fp16 matrix peak of one MI355X: 256 CUs x 4096 flop/clk x 2.4 GHz = 2.5 PFLOP/s
+  constexpr double kPeakTflops = 2500.0;
+  const double tflops = flops / ms * 1e-9;
+  std::cout << "Benchmark '" << name << "' took " << ms << " [ms]  (" << tflops << " TFLOP/s, "
+            << 100.0 * tflops / (kPeakTflops * gpus) << " % of the fp16 MFMA peak of " << gpus << " GPU(s))" << std::endl;
 }
 
 int run_tests() {
@@ -199,7 +203,7 @@ int run_shape_bench(const Shape& s, int gpus) {
   for (int i = 0; i < 3; ++i) sweep();
   const int reps = 10;
   const double ms = time_ms([&] { for (int i = 0; i < reps; ++i) sweep(); }) / reps;
-  report("mma_qreg_async on " + std::to_string(slabs.size()) + " GPU(s)", ms, s, heads);
+  report("mma_qreg_async on " + std::to_string(slabs.size()) + " GPU(s)", ms, s, heads, static_cast<int>(slabs.size()));
   return EXIT_SUCCESS;
 }
 

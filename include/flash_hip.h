@@ -10,6 +10,10 @@
  * Conventions
  *   - All tensors are contiguous [B, H, N, d] (reference flash/kernel_mma_qreg.cuh:30-34:
  *     qkv_offset = (b*H + h)*N*d); K and V have the shape of Q; O has the shape of Q.
+ *   - Tensor pointers need only the alignment of their element type.  The fast kernels (fp16 and
+ *     bfloat16 with d % 8 == 0, flash_fwd_f32_ws) move 16 bytes per lane and are used when q, k, v and o
+ *     all start on a 16-byte boundary (any whole allocation does); otherwise fp16 and fp32 tensors take
+ *     the slower element-staging kernel, bfloat16 tensors are rejected (INVALID_ARGUMENT).
  *   - Device = the calling thread's current HIP device.  `hip_stream` is a hipStream_t (NULL = the
  *     default stream).  Calls enqueue work and return; they never synchronise, allocate or free.
  *   - Return value: FLASH_HIP_OK (0) or a negative flash_hip_status.  The text of the last error of
@@ -69,7 +73,17 @@ typedef struct flash_launch_info {
   uint32_t staging;      /* 0 = register-staged element loads, 1 = register-staged 128-bit loads,
                             2 = direct global->LDS loads (buffer_load ... lds) */
   uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */
+  uint32_t persistent;   /* 1: the work items (grid_x * grid_y * grid_z of them) are walked by a persistent
+                            kernel launched as a 1-D grid of min(items, compute units rounded down to a
+                            multiple of 8) workgroups; 0: one workgroup per item, 1-D grid of all items */
 } flash_launch_info;
+
+/* Which entry point a geometry query describes. */
+typedef enum flash_hip_entry {
+  FLASH_ENTRY_F16 = 0,  /* flash_fwd_f16, and flash_fwd_f32_ws with a workspace (same kernels) */
+  FLASH_ENTRY_BF16 = 1, /* flash_fwd_bf16 */
+  FLASH_ENTRY_F32 = 2   /* flash_fwd_f32, and flash_fwd_f32_ws without a usable workspace */
+} flash_hip_entry;
 
 /*
  * fp16 attention forward: O = softmax(Q K^T * softmax_scale) V per (b, h), non-causal, no mask.
@@ -134,9 +148,16 @@ int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d
 /*
  * Geometry query; does not touch the GPU.  Replaces KernelParametersFactory::create
  * (flash/KernelParameters.hpp:383-422) for the native kernel.  Same error codes as flash_fwd_f16.
+ * Describes the launch flash_fwd_f16 makes for 16-byte-aligned tensors (the reference's factory takes
+ * no dtype either); flash_fwd_query_entry does the same for a named entry point.
  */
 int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type,
                     flash_launch_info* out);
+
+/* As flash_fwd_query, for the entry point `entry` (a flash_hip_entry): fp32 callers without a
+ * workspace run the element-staging kernel (staging 0, three-slot LDS rings, never persistent). */
+int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, int entry,
+                          flash_launch_info* out);
 
 /* Name of a kernel type as the reference's to_string prints it (flash/launch.hpp:28-46); NULL if
  * out of range. */

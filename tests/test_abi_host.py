@@ -49,6 +49,41 @@ def test_geometry_query(fa):
     assert info.tile_size[2] == 128 and info.staging == 0 and not info.aligned_rows
 
 
+def test_geometry_query_per_entry_point(fa):
+    """The query describes what each entry point launches: whole-tile fp16 / bf16 shapes are walked by
+    the persistent kernel (four-slot rings), ragged ones by one workgroup per item (three-slot rings),
+    and fp32 callers without scratch always stage elements through registers."""
+    f16 = fa.launch_info(4, 96, 1024, 128)
+    assert f16.persistent and f16.sram_size == 2 * 4 * 64 * 256 and f16.staging == 2
+    ragged = fa.launch_info(4, 96, 1000, 128)
+    assert not ragged.persistent and ragged.sram_size == 2 * 3 * 64 * 256
+    bf = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_BF16)
+    assert bf == f16
+    f32 = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_F32)
+    assert not f32.persistent and f32.staging == 0 and f32.sram_size == 2 * 3 * 64 * 256
+    assert f32.grid_dim == f16.grid_dim and f32.block_dim == (64, 4)
+    with pytest.raises(ValueError, match="multiple of 8"):
+        fa.launch_info(1, 1, 64, 50, fa.KernelType.mma_qreg, entry=fa.ENTRY_BF16)
+    with pytest.raises(ValueError, match="entry point"):
+        fa.launch_info(1, 1, 64, 64, entry=7)
+
+
+def test_bench_parent_launches_ranks_and_reports_their_failure(fa):
+    """`python bench.py --gpus 2` as one plain process starts two rank processes itself.  Without a GPU
+    every rank stops with "needs a HIP device"; the parent must come back non-zero, print no JSON line,
+    and never initialise a GPU itself."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test of the same path")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""
+    assert out.stderr.count("needs a HIP device") == 2, out.stderr[-2000:]
+
+
 def test_argument_errors_mirror_reference(fa):
     # reference flash/launch.cu:267-269 (odd d), :284-286 / :301-303 (d % 4), :270-280 (d > 128), :317
     with pytest.raises(ValueError, match="even"):

@@ -248,6 +248,85 @@ def test_full_size_properties(fa, oracle, torch_gpu, shape):
     assert float((o2.float() - of).abs().max()) <= ATOL
 
 
+# The long end of the sequence sweep and the per-GPU shard of the 8-GPU configuration: 1.6 GB and 0.8 GB
+# per tensor, so the last heads sit beyond byte offset 2^31 (the reference's 32-bit qkv_offset,
+# flash/kernel_mma_qreg.cuh:34, would wrap there).  Sampled heads against the CPU oracle.
+LONG = [(4, 96, 8192, 128), (4, 96, 16384, 128), (8, 96, 4096, 128)]
+
+
+@pytest.mark.parametrize("shape", LONG, ids=str)
+def test_long_sequences_and_shard_sampled_heads(fa, oracle, torch_gpu, shape):
+    torch = torch_gpu
+    B, H, N, d = shape
+    gen = torch.Generator(device="cuda:0").manual_seed(N + B)
+    q, k, v = (torch.empty(shape, device="cuda:0", dtype=torch.float16) for _ in range(3))
+    for t in (q, k, v):                      # batch by batch: no fp32 copy of a whole tensor
+        for b in range(B):
+            t[b] = torch.randn((H, N, d), device="cuda:0", generator=gen).half()
+    o = fa.forward(q, k, v, fa.KernelType.mma_qreg_async)
+    assert (B * H - 1) * N * d * 2 >= 2 ** 31   # the last head really is past the 32-bit range
+    for (b, h) in [(0, 0), (B // 2, H // 3), (B - 1, H - 1)]:
+        qs, ks, vs = (x[b:b + 1, h:h + 1].float().cpu().numpy() for x in (q, k, v))
+        ref = oracle.attn_naive(qs, ks, vs)
+        assert_close(o[b, h].float().cpu().numpy(), ref[0, 0], f"{shape} head ({b},{h})")
+    assert not torch.isnan(o).any()
+    del q, k, v, o
+    torch.cuda.empty_cache()
+
+
+def test_input_scale_one_and_a_half_sigma(fa, oracle, torch_gpu):
+    """Inputs at 1.5 standard deviations (scores 2.25 times as spread as unit-scale data): the
+    allclose form of the bar, |res - ref| <= 2e-3 + 1e-2*|ref|, as the reference's runner states its
+    own (main.cpp:49), over fp16 and both fp32 entry points and ragged / whole-tile shapes."""
+    torch = torch_gpu
+    for shape in ((2, 3, 512, 128), (1, 4, 700, 128), (2, 2, 768, 64), (1, 2, 333, 72)):
+        rng = np.random.default_rng(shape[2])
+        q, k, v = (oracle.round_f16((rng.standard_normal(shape) * 1.5).astype(np.float32)) for _ in range(3))
+        ref = oracle.attn_naive(q, k, v).astype(np.float64)
+        for dtype, ws in ((torch.float16, False), (torch.float32, False), (torch.float32, True)):
+            o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws).astype(np.float64)
+            err = np.abs(o - ref)
+            assert (err <= 2e-3 + 1e-2 * np.abs(ref)).all(), f"{shape} {dtype} ws={ws}: max-abs {err.max():.3e}"
+            print(f"1.5 sigma {shape} {dtype} ws={ws}: max-abs {err.max():.3e}")
+
+
+def test_tensors_that_start_off_a_16_byte_boundary(fa, oracle, torch_gpu):
+    """Views that begin one element into an allocation (2- or 4-byte aligned): the library must route
+    them to the element-staging kernel (the fast kernels move 16 bytes per lane); bfloat16 has no such
+    kernel and is refused."""
+    torch = torch_gpu
+    L = fa.lib()
+    shape = (2, 3, 300, 64)
+    B, H, N, d = shape
+    n = B * H * N * d
+    rng = np.random.default_rng(99)
+    host = [oracle.round_f16(rng.standard_normal(shape).astype(np.float32)) for _ in range(3)]
+    ref = oracle.attn_naive(*host)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dtype, fn, ws in ((torch.float16, L.flash_fwd_f16, False), (torch.float32, L.flash_fwd_f32, False),
+                          (torch.float32, L.flash_fwd_f32_ws, True)):
+        bufs = [torch.zeros(n + 8, dtype=dtype, device="cuda:0") for _ in range(4)]
+        views = [b[1:1 + n].view(shape) for b in bufs]
+        for t, x in zip(views, host):
+            t.copy_(torch.from_numpy(x).to("cuda:0", dtype))
+        assert all(t.data_ptr() % 16 != 0 for t in views)
+        args = [t.data_ptr() for t in views] + [B, H, N, d, 1.0 / np.sqrt(d), 11]
+        if ws:
+            need = L.flash_fwd_f32_workspace_bytes(B, H, N, d, 11)
+            wbuf = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+            rc = fn(*args, wbuf.data_ptr(), need, stream)
+        else:
+            rc = fn(*args, stream)
+        assert rc == 0, L.flash_hip_last_error()
+        torch.cuda.synchronize()
+        assert_close(views[3].float().cpu().numpy(), ref, f"unaligned {dtype} ws={ws}")
+        assert float(bufs[3][0]) == 0.0 and float(bufs[3][n + 1]) == 0.0   # nothing written outside the view
+    b16 = [torch.zeros(n + 8, dtype=torch.bfloat16, device="cuda:0") for _ in range(4)]
+    ptrs = [b[1:].data_ptr() for b in b16]
+    assert L.flash_fwd_bf16(*ptrs, B, H, N, d, 0.125, 11, stream) == -1
+    assert b"aligned" in L.flash_hip_last_error()
+
+
 def test_python_wrapper_matches_reference_semantics(fa, oracle, torch_gpu):
     """flash-attention_amd.forward: new tensor, inputs untouched, fp32 in -> fp32 out, non-contiguous ok."""
     torch = torch_gpu
