@@ -67,7 +67,8 @@ class LaunchInfo:
 
 # every symbol include/flash_hip.h declares
 ABI_SYMBOLS = (
-    "flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_ws", "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
+    "flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_ws",
+    "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
     "flash_fwd_query_entry",
     "flash_kernel_type_name",
     "flash_hip_last_error", "flash_hip_version",

@@ -78,7 +78,14 @@ struct FwdParams {
   int d;              // head dim (<= D)
   int nqt;            // query tiles per head = ceil(N / kBr)
   uint32_t total_wg;  // B * H * nqt
-  float scale_log2e;  // softmax_scale * log2(e)
+  // softmax_scale * log2(e) = q_scale * s_scale.  q_scale is a power of two: multiplying Q by it is
+  // exact in 16-bit floating point, so the matrix cores see the caller's Q bit for bit (shifted);
+  // s_scale in [1, 2) multiplies the fp32 scores just before the exponential.  (One rounding of
+  // Q * softmax_scale * log2(e) to fp16 would be cheaper by one multiply per score, but it perturbs
+  // every score by 2^-11 relative and was measured to be the largest error term of the kernel by far.)
+  float q_scale;
+  float s_scale;
+  float defer_thr;    // kDeferLog2 / s_scale: the deferral threshold in units of the unscaled scores
 #if defined(FLASH_PHASE_STAMPS)
   unsigned long long* stamps;  // diagnostic builds only: 8 values per wave (see tools/README.md)
 #endif
@@ -345,14 +352,22 @@ __device__ __forceinline__ f16x8 read_k_frag(uint32_t koff, const LaneAddr<D>& l
 }
 
 // Running softmax state of one lane for one of its query blocks: the query is lane & 31 of that
-// block, the keys are those of the lane's half-wave.  Scores leave the MFMAs already multiplied by
-// softmax_scale * log2(e) (Q is pre-scaled) and RELATIVE to the reference `mc` (a rank-1 MFMA
-// k-step adds -mc to every key of the query), so the exponential reads the accumulator directly.
+// block, the keys are those of the lane's half-wave.  Scores leave the MFMAs multiplied by the
+// power-of-two part of softmax_scale * log2(e) (Q is pre-scaled, exactly) and RELATIVE to the
+// reference `mc` (a rank-1 MFMA k-step adds -mc to every key of the query); the exponential takes the
+// accumulator times the remaining factor s_scale.  mc, mx_next and the deferral threshold are in
+// accumulator units (exp2 units / s_scale).
 struct SoftmaxState {
-  float mc;       // reference, in exp2 units, that S, P, l and O are relative to
+  float mc;       // reference that S, P, l and O are relative to
   float l;        // this lane's partial row sum at that scale
   float alpha;    // factor still to be applied to O (valid while the wave's `pending` flag is set)
   float mx_next;  // max of the next block's relative scores over this lane's keys
+};
+
+// Softmax scale factors as the pipeline steps use them (FwdParams::s_scale, ::defer_thr).
+struct ScaleSplit {
+  float c;    // residual factor applied to the fp32 scores before exp2
+  float thr;  // deferral threshold in accumulator units
 };
 
 // How far (in exp2 units) a score may exceed the reference before the state is moved to a new
@@ -436,7 +451,8 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uin
                                               f16x8 (&ka)[Geom<D>::kKHold], f32x16 (&o)[kQB][Geom<D>::kDvBlocks],
                                               const f32x16 (&s_cur)[kQB], f32x16 (&s_nxt)[kQB],
                                               const f16x8 (&p_prev)[kQB][2], f16x8 (&p_cur)[kQB][2],
-                                              SoftmaxState (&st)[kQB], int kv_next0, int N, int lane) {
+                                              SoftmaxState (&st)[kQB], const ScaleSplit sc, int kv_next0, int N,
+                                              int lane) {
   using G = Geom<D>;
   constexpr int KS = G::kKSteps;
   constexpr int KH = G::kKHold;
@@ -497,7 +513,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uin
 #pragma unroll
     for (int g = n * ELEMS / SLOTS; g < (n + 1) * ELEMS / SLOTS; ++g) {
       if (g > 0) finish(g - 1);
-      t_exp = fast_exp2(s_cur[g / 16][g % 16]);
+      t_exp = fast_exp2(s_cur[g / 16][g % 16] * sc.c);
       asm volatile("" : "+v"(t_exp));
     }
   };
@@ -588,13 +604,14 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb, uin
 // 2^-d; the bias fragment of the rank-1 k-step is rebuilt.
 template <int D, bool HAS_NEXT>
 __device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], SoftmaxState (&st)[kQB],
-                                         f16x8 (&bq)[kQB], f32x16 (&s_nxt)[kQB], bool& pending, int lane) {
+                                         f16x8 (&bq)[kQB], f32x16 (&s_nxt)[kQB], bool& pending, const ScaleSplit sc,
+                                         int lane) {
   bool any_need = false;
   if constexpr (HAS_NEXT) {
     float mxx = st[0].mx_next;
 #pragma unroll
     for (int q = 1; q < kQB; ++q) mxx = fmaxf(mxx, st[q].mx_next);
-    any_need = __builtin_amdgcn_ballot_w64(mxx > kDeferLog2) != 0;
+    any_need = __builtin_amdgcn_ballot_w64(mxx > sc.thr) != 0;
   }
   if (__builtin_expect(pending || any_need, 0)) {  // rare: keep it out of the fall-through path
     if (pending) {
@@ -610,7 +627,7 @@ __device__ __forceinline__ void step_end(f32x16 (&o)[kQB][Geom<D>::kDvBlocks], S
         const float rise = fmaxf(fmaxf(mp.lo, mp.hi), 0.f);  // references only move up
         const SplitRef r = split_ref(st[q].mc + rise);
         const float d = r.eff - st[q].mc;
-        st[q].alpha = fast_exp2(-d);  // 1 for rows whose reference does not move
+        st[q].alpha = fast_exp2(-d * sc.c);  // 1 for rows whose reference does not move
         st[q].mc = r.eff;
         st[q].l *= st[q].alpha;
 #pragma unroll
@@ -760,13 +777,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
         const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
         qf[q][ks] = __builtin_bit_cast(f16x8, raw);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.scale_log2e);
+        for (int j = 0; j < 8; ++j) qf[q][ks][j] = (f16)((float)qf[q][ks][j] * p.q_scale);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const uint32_t off =
               (col + j < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)(col + j)) * (uint32_t)sizeof(T) : kOob;
-          qf[q][ks][j] = (f16)((float)load_elem<T>(q_rs, off) * p.scale_log2e);
+          qf[q][ks][j] = (f16)((float)load_elem<T>(q_rs, off) * p.q_scale);
         }
       }
     }
@@ -828,6 +845,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (f16)((lane < 32 && j < 2) ? 1.f : 0.f);
   bool pending = false;
+  const ScaleSplit sc{p.s_scale, p.defer_thr};
 #pragma unroll
   for (int q = 0; q < kQB; ++q) {
     mask_scores(sA[q], 0, N, lane);
@@ -887,11 +905,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel(const FwdParams p
     const uint32_t v_cur = (uint32_t)(s0 * G::kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * G::kTileBytes);
     pipeline_step<D, !FAST, true, !LAST, MASKED>(dma_hook, k_cur + kBlk, v_prv + kBlk, k_nxt, la, ones, bq, qf, ka, o, sA,
-                                                 sB, pB, pA, st, t * kBc + 32, N, lane);
-    step_end<D, true>(o, st, bq, sB, pending, lane);
+                                                 sB, pB, pA, st, sc, t * kBc + 32, N, lane);
+    step_end<D, true>(o, st, bq, sB, pending, sc, lane);
     pipeline_step<D, !FAST, !LAST, !LAST, MASKED>(no_hook, k_nxt, v_cur, k_nxt + kBlk, la, ones, bq, qf, ka, o, sB, sA, pA,
-                                                  pB, st, (t + 1) * kBc, N, lane);
-    step_end<D, !LAST>(o, st, bq, sA, pending, lane);
+                                                  pB, st, sc, (t + 1) * kBc, N, lane);
+    step_end<D, !LAST>(o, st, bq, sA, pending, sc, lane);
     staged_barrier();
   };
   using std::integral_constant;

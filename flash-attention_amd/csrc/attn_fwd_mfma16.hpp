@@ -147,13 +147,40 @@ constexpr int kPvFirst = 2;       // O  = V^T P^T (first product of an item)
 // sum of the lane's own four fp16 values, accumulated in fp32: one 2-pass MFMA replaces the vector adds
 // of four probabilities, exactly.
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
-template <int EK = kF16>
-__device__ __forceinline__ void mfma_rowsum(f32x4& acc, const f16x4v& ones, const f16x4v& p4) {
-  if constexpr (EK == kBF16) {
-    asm volatile("v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(ones), "v"(p4));
-  } else {
-    asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(ones), "v"(p4));
+// The row sums of query block q live in fixed accumulation registers, right behind O^T and Q
+// (D = 128: a[192 + 4q ..], D = 64: a[96 + 4q ..]), named in the operand constraints.  Left to itself
+// the register allocator gives the four sums different registers in different pipeline steps and
+// rotates them with v_accvgpr moves inside the loop, next to matrix instructions whose result
+// latency it does not know.
+#define FLASH_LSUM_CASE(Q, REGS128, REGS64, TEXT, ...)                   \
+  case Q:                                                                 \
+    if constexpr (D == 128) {                                             \
+      asm volatile(TEXT : "+{" REGS128 "}"(acc) : __VA_ARGS__);          \
+    } else {                                                              \
+      asm volatile(TEXT : "+{" REGS64 "}"(acc) : __VA_ARGS__);           \
+    }                                                                     \
+    break;
+#define FLASH_LSUM_SWITCH(q, TEXT, ...)                                   \
+  switch (q) {                                                            \
+    FLASH_LSUM_CASE(0, "a[192:195]", "a[96:99]", TEXT, __VA_ARGS__)       \
+    FLASH_LSUM_CASE(1, "a[196:199]", "a[100:103]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(2, "a[200:203]", "a[104:107]", TEXT, __VA_ARGS__)     \
+    default:                                                              \
+    FLASH_LSUM_CASE(3, "a[204:207]", "a[108:111]", TEXT, __VA_ARGS__)     \
   }
+// `q` must be a compile-time constant at the call site after inlining (the other cases fold away).
+template <int D, int EK = kF16>
+__device__ __forceinline__ void mfma_rowsum(f32x4& acc, int q, const f16x4v& ones, const f16x4v& p4) {
+  if constexpr (EK == kBF16) {
+    FLASH_LSUM_SWITCH(q, "v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0", "v"(ones), "v"(p4))
+  } else {
+    FLASH_LSUM_SWITCH(q, "v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0", "v"(ones), "v"(p4))
+  }
+}
+// The accumulation registers of query block q's row sum, tied to their place (no instruction).
+template <int D>
+__device__ __forceinline__ void pin_lsum(f32x4& acc, int q) {
+  FLASH_LSUM_SWITCH(q, "", "n"(0))
 }
 
 // Two floats to one register of packed 16-bit values of kind EK, round to nearest even
@@ -263,9 +290,8 @@ __device__ __forceinline__ f16x8 read_v(uint32_t voff, const LaneAddr<D>& la, in
 }
 
 struct State {
-  float mc;       // reference, exp2 units, of the lane's query in this query block
+  float mc;       // reference of the lane's query in this query block, in accumulator units (exp2 units / s_scale)
   float alpha;    // pending O factor
-  float mx_next;  // max of the next block's relative scores over this lane's keys
 };
 
 // Register i of S^T tile kb holds key kv0 + 16*kb + 4*g + i.
@@ -286,20 +312,19 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
                                               const f16x8 (&qf)[kQ16][Cfg<D>::kKS], f16x8 (&ka)[4],
                                               f32x4 (&o)[kQ16][Cfg<D>::kDv16], const f32x4 (&s_cur)[2][kQ16],
                                               f32x4 (&s_nxt)[2][kQ16], const f16x8 (&p_prev)[kQ16],
-                                              f16x8 (&p_cur)[kQ16], State (&st)[kQ16], f32x4 (&lsum)[kQ16],
+                                              f16x8 (&p_cur)[kQ16], float& mx_all, f32x4 (&lsum)[kQ16],
+                                              const ScaleSplit sc, const uint64_t pending, uint64_t& vote,
                                               int kv_next0, int N, int lane) {
   constexpr int kKS = Cfg<D>::kKS, kDv16 = Cfg<D>::kDv16;
   constexpr int QK_SLOTS = 2 * kKS * kQ16;  // 32 (D = 128), 16 (D = 64)
   constexpr int PV_SLOTS = kDv16 * kQ16;    // 32, 16
   constexpr int SLOTS = QK_SLOTS + PV_SLOTS;
   constexpr int ELEMS = 8 * kQ16;           // scores per lane and step
-  constexpr int MAX_OPS = 4 * kQ16;
+  constexpr int MAX_OPS = ELEMS / 2;        // one running maximum over all scores: 3 values, then 2 per op
   constexpr int MAX_DELAY = 2;
 
   f16x8 va[4];
-  float mx[kQ16];
-#pragma unroll
-  for (int q = 0; q < kQ16; ++q) mx[q] = 0.f;
+  float mx = 0.f;
 
   // exp(j), software-pipelined over the slots.  Element g = 8q + e: key block e / 4, register e % 4.
   float t_exp = 0.f, t_exp_prev = 0.f;
@@ -319,7 +344,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     } else {
       p4 = __builtin_shufflevector(p_cur[q], p_cur[q], 4, 5, 6, 7);
     }
-    mfma_rowsum<EK>(lsum[q], ones4, p4);
+    mfma_rowsum<D, EK>(lsum[q], q, ones4, p4);
   };
   auto finish = [&](int g) __attribute__((always_inline)) {
     const int q = g / 8, e = g % 8;
@@ -332,35 +357,51 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     }
     t_exp_prev = t_exp;
   };
+  // The residual scale factor is one v_mul_f32 per score (a packed v_pk_mul_f32 issues in twice the
+  // time of a plain multiply on this chip, so pairing gains nothing), issued one score ahead of the
+  // exponential that consumes it so that the exponential never waits for its operand.
+  float x_cur = 0.f, x_nxt = 0.f;
+  auto scaled = [&](int g) __attribute__((always_inline)) {
+    // (no register pin here: an asm statement that names the product makes the compiler pad the
+    // exponential behind it with a wait state)
+    return s_cur[(g % 8) / 4][g / 8][g % 4] * sc.c;
+  };
   auto exp_share = [&](int n) __attribute__((always_inline)) {
 #pragma unroll
     for (int g = n * ELEMS / SLOTS; g < (n + 1) * ELEMS / SLOTS; ++g) {
       if (g > 0) finish(g - 1);
-      t_exp = fast_exp2(s_cur[(g % 8) / 4][g / 8][g % 4]);
+      if (g == 0) x_cur = scaled(0);
+      t_exp = fast_exp2(x_cur);
       asm volatile("" : "+v"(t_exp));
+      if (g + 1 < ELEMS) x_nxt = scaled(g + 1);
+      x_cur = x_nxt;
     }
   };
-  // in-lane max micro-op u of s_nxt: query block u / 4; the 8 values are tile 0 regs 0..3, tile 1 regs 0..3
+  // In-lane maximum of the next block's scores, all query blocks in one chain: the hot path only asks
+  // whether ANY score of the wave exceeds the deferral threshold (the rare path works out which query
+  // moved).  Value v = 8q + e is register e % 4 of tile e / 4 of query block q; op 0 folds values 0..2,
+  // op u values 2u+1 and 2u+2, the last op value 31.
+  auto score = [&](int v) __attribute__((always_inline)) { return s_nxt[(v % 8) / 4][v / 8][v % 4]; };
   auto max_op = [&](int u) __attribute__((always_inline)) {
-    const int q = u / 4, k = u % 4;
-    const f32x4& t0 = s_nxt[0][q];
-    const f32x4& t1 = s_nxt[1][q];
-    if (k == 0) {
-      if constexpr (MASKED) {
-        mask_tile(s_nxt[0][q], kv_next0, N, lane);
-        mask_tile(s_nxt[1][q], kv_next0 + 16, N, lane);
+    if constexpr (MASKED) {
+      // keys beyond N of a query block, right before the chain first touches the block
+      const int q_new = u == 0 ? 0 : ((2 * u + 2) % 8 == 0 ? (2 * u + 2) / 8 : -1);
+      if (q_new >= 0 && q_new < kQ16) {
+        mask_tile(s_nxt[0][q_new], kv_next0, N, lane);
+        mask_tile(s_nxt[1][q_new], kv_next0 + 16, N, lane);
       }
-      mx[q] = fmaxf(fmaxf(t0[0], t0[1]), t0[2]);
-    } else if (k == 1) {
-      mx[q] = fmaxf(fmaxf(mx[q], t0[3]), t1[0]);
-    } else if (k == 2) {
-      mx[q] = fmaxf(fmaxf(mx[q], t1[1]), t1[2]);
+    }
+    if (u == 0) {
+      mx = fmaxf(fmaxf(score(0), score(1)), score(2));
+    } else if (2 * u + 2 < ELEMS) {
+      mx = fmaxf(fmaxf(mx, score(2 * u + 1)), score(2 * u + 2));
     } else {
-      st[q].mx_next = fmaxf(mx[q], t1[3]);
-      asm volatile("" : "+v"(st[q].mx_next));
+      mx = fmaxf(mx, score(ELEMS - 1));
+      mx_all = mx;
+      asm volatile("" : "+v"(mx_all));
       return;
     }
-    asm volatile("" : "+v"(mx[q]));
+    asm volatile("" : "+v"(mx));
   };
 
   // ---- QK slots: key block kb, k-step ks, query block q; K fragment index f = 4 kb + ks -------------
@@ -420,13 +461,29 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     }
   }
   finish(ELEMS - 1);
-  asm volatile("s_nop 1" ::: "memory");  // the last pair was packed by the instruction just before
+  // The last pair was packed by the instruction just before; the row-sum MFMA that reads it needs two
+  // wait states.  They are filled with the step's vote: one vector compare (any lane whose maximum
+  // exceeds the deferral threshold) joined with the pending-rescale mask by one scalar OR.  Written
+  // out: from `pending || ballot(...)` the compiler builds the same condition out of five scalar
+  // instructions, and at one wave per SIMD every instruction is issue time.
+  if constexpr (HAS_QK) {
+    asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_or_b64 %0, vcc, %3"
+                 : "=s"(vote)
+                 : "s"(sc.thr), "v"(mx_all), "s"(pending)
+                 : "vcc", "scc", "memory");
+  } else {
+    vote = pending;
+    asm volatile("s_nop 1" ::: "memory");
+  }
   group_add(ELEMS / 4 - 1);
 }
 
 // Wait states before the row sums are read by anything but the MFMA that accumulates them.
+template <int D>
 __device__ __forceinline__ void drain_lsum(f32x4 (&lsum)[kQ16]) {
-  asm volatile("s_nop 7" : "+a"(lsum[0]), "+a"(lsum[1]), "+a"(lsum[2]), "+a"(lsum[3]));
+  asm volatile("s_nop 7" ::: "memory");
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) pin_lsum<D>(lsum[q], q);
 }
 
 // The bias registers are written by the vector ALU and read as srcC by MFMAs that the compiler does not
@@ -437,35 +494,43 @@ __device__ __forceinline__ void bias_ready(f32x4 (&bias)[kQ16]) {
 
 // Between two steps: pending O rescale, then the decision whether the next block moves a reference.
 template <int NB, bool HAS_NEXT>
-__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], f32x4 (&lsum)[kQ16],
-                                         f32x4 (&bias)[kQ16], f32x4 (&s_nxt)[2][kQ16], bool& pending, int lane) {
-  bool any_need = false;
-  if constexpr (HAS_NEXT) {
-    const float mxx = fmaxf(fmaxf(st[0].mx_next, st[1].mx_next), fmaxf(st[2].mx_next, st[3].mx_next));
-    any_need = __builtin_amdgcn_ballot_w64(mxx > kDeferLog2) != 0;
-  }
-  if (__builtin_expect(pending || any_need, 0)) {
-    if (pending) {
+__device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], const float mx_all,
+                                         f32x4 (&lsum)[kQ16], f32x4 (&bias)[kQ16], f32x4 (&s_nxt)[2][kQ16],
+                                         uint64_t& pending, const uint64_t vote, const ScaleSplit sc, int lane) {
+  // `vote` = pending-rescale mask | lanes whose next-block maximum exceeds the threshold (pipeline_step)
+  if (__builtin_expect(vote != 0, 0)) {
+    bool any_need = false;
+    if constexpr (HAS_NEXT) any_need = __builtin_amdgcn_ballot_w64(mx_all > sc.thr) != 0;
+    if (pending != 0) {
       drain_o(o);
 #pragma unroll
       for (int q = 0; q < kQ16; ++q) {
+        const float al = st[q].alpha;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
+          // one tile at a time, fenced: the accumulators pass through vector registers for the multiply,
+          // and left alone the compiler reads dozens of them ahead, which this rare path cannot afford
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[q][b][i] *= st[q].alpha;
+          for (int i = 0; i < 4; ++i) o[q][b][i] *= al;
+          asm volatile("" : "+a"(o[q][b]));
         }
       }
     }
-    pending = false;
+    pending = 0;
     if (any_need) {
-      drain_lsum(lsum);
+      drain_lsum<NB * 16>(lsum);
 #pragma unroll
       for (int q = 0; q < kQ16; ++q) {
-        const float rise = fmaxf(quad_lane_max(st[q].mx_next, lane), 0.f);  // references only move up
-        st[q].alpha = fast_exp2(-rise);
+        // this query block's own maximum (keys beyond N already carry -inf)
+        const f32x4 &t0 = s_nxt[0][q], &t1 = s_nxt[1][q];
+        const float mq = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
+                               fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
+        const float rise = fmaxf(quad_lane_max(mq, lane), 0.f);  // references only move up
+        st[q].alpha = fast_exp2(-rise * sc.c);
         st[q].mc += rise;
 #pragma unroll
         for (int i = 0; i < 4; ++i) lsum[q][i] *= st[q].alpha;
+        pin_lsum<NB * 16>(lsum[q], q);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           s_nxt[0][q][i] -= rise;
@@ -474,7 +539,7 @@ __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16]
         }
       }
       bias_ready(bias);
-      pending = true;
+      pending = ~0ull;
     }
   }
 }
@@ -541,19 +606,18 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
   }
 }
 
-// One register of two packed Q values times softmax_scale * log2(e), rounded once to 16 bits.
-//  fp16: v_fma_mix reads the halves as fp16, multiplies in fp32 and rounds back (two instructions);
+// One register of two packed Q values times `sc`, the power-of-two part of softmax_scale * log2(e):
+// exact in both 16-bit formats (only values that land in the subnormal range lose bits, an absolute
+// error below 2^-25).
+//  fp16: one packed multiply by sc in both halves;
 //  bf16: the halves are widened by shifts / masks, multiplied in fp32 and packed by v_cvt_pk_bf16_f32.
 template <int EK>
 __device__ __forceinline__ uint32_t scale_q2(uint32_t x, float sc) {
   if constexpr (EK == kBF16) {
     return pack2<kBF16>(__uint_as_float(x << 16) * sc, __uint_as_float(x & 0xFFFF0000u) * sc);
   } else {
-    asm("v_fma_mixlo_f16 %0, %0, %1, 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mixhi_f16 %0, %0, %1, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : "+v"(x)
-        : "v"(sc));
-    return x;
+    const f16x2 s2 = {(f16)sc, (f16)sc};
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, x) * s2);
   }
 }
 
@@ -581,6 +645,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   const int n16 = lane & 15;
   const int g = lane >> 4;
   const int N = p.N, d = p.d;
+  const ScaleSplit sc{p.s_scale, p.defer_thr};
 
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
@@ -655,7 +720,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     for (int ks = 0; ks < kKS; ++ks) {
       u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], p.scale_log2e);
+      for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], p.q_scale);
       qf[q][ks] = __builtin_bit_cast(f16x8, w);
     }
   }
@@ -705,9 +770,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   }
   drain_s(sA);
   State st[kQ16];
+  float mx_all = 0.f;  // in-lane maximum of the block whose scores were computed last
+  uint64_t vote = 0;   // see pipeline_step / step_end
   f32x4 bias[kQ16];
   f32x4 lsum[kQ16];  // row sums, every register of a lane holds the same partial sum (see mfma_rowsum)
-  bool pending = false;
+  uint64_t pending = 0;
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {
     mask_tile(sA[0][q], 0, N, lane);
@@ -724,9 +791,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     st[q].mc = mc;
 #pragma unroll
     for (int i = 0; i < 4; ++i) lsum[q][i] = 0.f;
-    asm volatile("" : "+a"(lsum[q]));
+    pin_lsum<D>(lsum[q], q);
     st[q].alpha = 1.f;
-    st[q].mx_next = 0.f;
   }
   bias_ready(bias);
 
@@ -756,11 +822,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const uint32_t v_cur = (uint32_t)(s0 * kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * kTileBytes);
     pipeline_step<D, true, !LAST, MASKED, kPvAccumulate, EK>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
-                                       pB, pA, st, lsum, t * kBc + 32, N, lane);
-    step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
-    pipeline_step<D, !LAST, !LAST, MASKED, kPvAccumulate, EK>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st,
-                                        lsum, (t + 1) * kBc, N, lane);
-    step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
+                                       pB, pA, mx_all, lsum, sc, pending, vote, t * kBc + 32, N, lane);
+    step_end<kDv16, true>(o, st, mx_all, lsum, bias, sB, pending, vote, sc, lane);
+    pipeline_step<D, !LAST, !LAST, MASKED, kPvAccumulate, EK>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all,
+                                        lsum, sc, pending, vote, (t + 1) * kBc, N, lane);
+    step_end<kDv16, !LAST>(o, st, mx_all, lsum, bias, sA, pending, vote, sc, lane);
     staged_barrier();
   };
   using std::integral_constant;
@@ -786,7 +852,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       for (int q = 0; q < kQ16; ++q) mfma_o<true, EK>(o[q][b], vf, pB[q]);
     }
     drain_o(o);
-    drain_lsum(lsum);
+    drain_lsum<D>(lsum);
   }
 
   // ---- epilogue: O = O^T / l ---------------------------------------------------------------------------
@@ -868,6 +934,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const int n16 = lane & 15;
   const int g = lane >> 4;
   const int N = p.N, d = p.d;
+  const ScaleSplit sc{p.s_scale, p.defer_thr};
   const int nt = N / kBc;  // multiple of 4
 
   const size_t head_elems = (size_t)N * (size_t)d;
@@ -929,14 +996,14 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   };
   // pre-multiply by softmax_scale * log2(e); the registers come back as accumulation registers
   auto convert_q = [&]() __attribute__((always_inline)) {
-    const float sc = p.scale_log2e;
+    const float qs = p.q_scale;
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
       for (int ks = 0; ks < kKS; ++ks) {
         u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], sc);
+        for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], qs);
         qf[q][ks] = __builtin_bit_cast(f16x8, w);
         asm volatile("" : "+a"(qf[q][ks]));
       }
@@ -963,6 +1030,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   f16x8 pA[kQ16], pB[kQ16];
   f16x8 ka[4];
   State st[kQ16];
+  float mx_all = 0.f;  // in-lane maximum of the block whose scores were computed last
+  uint64_t vote = 0;   // see pipeline_step / step_end
   f32x4 bias[kQ16];
   f32x4 lsum[kQ16];
 
@@ -1000,7 +1069,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       }
     }
     drain_s(sA);
-    bool pending = false;
+    uint64_t pending = 0;
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
       float mx = fmaxf(fmaxf(sA[0][q][0], sA[0][q][1]), fmaxf(sA[0][q][2], sA[0][q][3]));
@@ -1015,10 +1084,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       st[q].mc = mc;
 #pragma unroll
       for (int i = 0; i < 4; ++i) lsum[q][i] = 0.f;
-      asm volatile("" : "+a"(lsum[q]));
+      pin_lsum<D>(lsum[q], q);
       st[q].alpha = 1.f;
-      st[q].mx_next = 0.f;
-    }
+      }
     bias_ready(bias);
 
     // ---- tile iterations; SLOT = t % 4 is a compile-time constant -------------------------------------
@@ -1061,16 +1129,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
       constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
       pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate, EK>(
-          dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, st, lsum, 0, N, lane);
-      step_end<kDv16, true>(o, st, lsum, bias, sB, pending, lane);
+          dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, mx_all, lsum, sc, pending, vote, 0, N, lane);
+      step_end<kDv16, true>(o, st, mx_all, lsum, bias, sB, pending, vote, sc, lane);
       if constexpr (LAST) {
         // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
         // loads have the last step, the last P V product and the output stores to land.
         if (has_next) fetch_q(next_item);
       }
       pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate, EK>(
-          no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, st, lsum, 0, N, lane);
-      step_end<kDv16, !LAST>(o, st, lsum, bias, sA, pending, lane);
+          no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all, lsum, sc, pending, vote, 0, N, lane);
+      step_end<kDv16, !LAST>(o, st, mx_all, lsum, bias, sA, pending, vote, sc, lane);
       if constexpr (LAST) {
         // wait for this wave's staging pieces, which are older than the Q loads, but not for those
         if (has_next) {
@@ -1114,7 +1182,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         for (int q = 0; q < kQ16; ++q) mfma_o<true, EK>(o[q][b], vf[b], pB[q]);
       }
       drain_o(o);
-      drain_lsum(lsum);
+      drain_lsum<D>(lsum);
     }
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {

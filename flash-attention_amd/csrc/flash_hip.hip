@@ -25,6 +25,10 @@ namespace {
 
 using namespace flash_hip;
 
+int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                        float softmax_scale, int kernel_type, void* workspace, int64_t workspace_bytes,
+                        void* hip_stream);
+
 thread_local char g_err[512] = "";
 
 int fail(int code, const char* fmt, ...) {
@@ -81,7 +85,8 @@ int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool 
 }
 
 
-// Kernel arguments of one call.  The kernels work in the exp2 domain: the softmax scale carries log2(e).
+// Kernel arguments of one call.  The kernels work in the exp2 domain: the softmax scale carries log2(e)
+// and is split into an exact power of two for Q and a residual factor for the scores.
 FwdParams make_params(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
                       float softmax_scale, const Plan& plan) {
   FwdParams prm{};
@@ -93,7 +98,18 @@ FwdParams make_params(const void* q, const void* k, const void* v, void* o, int6
   prm.d = (int)d;
   prm.nqt = (int)plan.nqt;
   prm.total_wg = (uint32_t)(B * H * (int64_t)plan.nqt);
-  prm.scale_log2e = softmax_scale * 1.44269504088896340736f;
+  // softmax_scale * log2(e) = 2^e * c with c in [1, 2); e is kept inside [-14, 0] so that Q * 2^e neither
+  // overflows fp16 nor needs more than the format's normal range (outside that window c takes the rest)
+  const float x = softmax_scale * 1.44269504088896340736f;
+  int e = 0;
+  if (x > 0.f && std::isfinite(x)) {
+    (void)std::frexp(x, &e);  // x = m * 2^e, m in [0.5, 1)
+    e -= 1;                   // x = (2m) * 2^(e-1)
+  }
+  e = e < -14 ? -14 : (e > 0 ? 0 : e);
+  prm.q_scale = std::ldexp(1.0f, e);
+  prm.s_scale = x / prm.q_scale;
+  prm.defer_thr = prm.s_scale > 0.f ? kDeferLog2 / prm.s_scale : kDeferLog2;
   return prm;
 }
 
@@ -242,6 +258,43 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   return plan.tile_d == 64 ? launch<64, T, false>(prm, plan.lds, stream) : launch<128, T, false>(prm, plan.lds, stream);
 }
 
+// fp32 tensors through scratch memory: one conversion pass into three fp16 copies, then the fp16
+// kernels with fp32 output.  `workspace` is device memory the caller (or the library's built-in
+// buffer) provides; nothing is allocated here.
+int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
+                        float softmax_scale, int kernel_type, void* workspace, int64_t workspace_bytes,
+                        void* hip_stream) {
+  Plan plan;
+  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
+  if (rc != FLASH_HIP_OK) return rc;
+  // rows without 16-byte chunks, no workspace, or tensors that do not start on a 16-byte boundary:
+  // convert while staging
+  if (!plan.fast || !workspace || !aligned16(q, k, v, o))
+    return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
+  if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
+  const int64_t each = ws_tensor_bytes(B, H, N, d);
+  if (workspace_bytes < kCastTensors * each)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace of %lld bytes is too small: %lld needed",
+                (long long)workspace_bytes, (long long)(kCastTensors * each));
+  if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  CastParams cp;
+  const void* src[kCastTensors] = {q, k, v};
+  for (int i = 0; i < kCastTensors; ++i) {
+    cp.src[i] = (const float*)src[i];
+    cp.dst[i] = (f16*)((char*)workspace + (int64_t)i * each);
+  }
+  cp.n4 = (uint64_t)(B * H * N * d / 4);
+  // enough workgroups to keep every CU's memory pipeline full, a few trips each at large sizes
+  const uint64_t trips = (cp.n4 + kCastThreads * 4 - 1) / (kCastThreads * 4);
+  const uint32_t gx = (uint32_t)(trips < 8192 ? (trips ? trips : 1) : 8192);
+  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, cp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
+  const FwdParams prm = make_params(cp.dst[0], cp.dst[1], cp.dst[2], o, B, H, N, d, softmax_scale, plan);
+  return launch_fast<float>(prm, plan, N, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -279,35 +332,7 @@ int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d
 
 int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
                      float softmax_scale, int kernel_type, void* workspace, int64_t workspace_bytes, void* hip_stream) {
-  Plan plan;
-  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
-  if (rc != FLASH_HIP_OK) return rc;
-  // rows without 16-byte chunks, no workspace, or tensors that do not start on a 16-byte boundary:
-  // convert while staging
-  if (!plan.fast || !workspace || !aligned16(q, k, v, o))
-    return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
-  if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  const int64_t each = ws_tensor_bytes(B, H, N, d);
-  if (workspace_bytes < kCastTensors * each)
-    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace of %lld bytes is too small: %lld needed",
-                (long long)workspace_bytes, (long long)(kCastTensors * each));
-  if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
-  hipStream_t stream = (hipStream_t)hip_stream;
-  CastParams cp;
-  const void* src[kCastTensors] = {q, k, v};
-  for (int i = 0; i < kCastTensors; ++i) {
-    cp.src[i] = (const float*)src[i];
-    cp.dst[i] = (f16*)((char*)workspace + (int64_t)i * each);
-  }
-  cp.n4 = (uint64_t)(B * H * N * d / 4);
-  // enough workgroups to keep every CU's memory pipeline full, a few trips each at large sizes
-  const uint64_t trips = (cp.n4 + kCastThreads * 4 - 1) / (kCastThreads * 4);
-  const uint32_t gx = (uint32_t)(trips < 8192 ? (trips ? trips : 1) : 8192);
-  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, cp);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
-  const FwdParams prm = make_params(cp.dst[0], cp.dst[1], cp.dst[2], o, B, H, N, d, softmax_scale, plan);
-  return launch_fast<float>(prm, plan, N, stream);
+  return forward_f32_scratch(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, workspace, workspace_bytes, hip_stream);
 }
 
 int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, flash_launch_info* out) {

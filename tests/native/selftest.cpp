@@ -273,6 +273,18 @@ static int bench_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps, int
   std::sort(times.begin(), times.end());
   const double med = times[times.size() / 2], mn = times[0];
   const double flops = 4.0 * B * H * (double)N * (double)N * d;
+  {
+    // the same launches back to back (no host synchronisation in between): the rate under sustained load
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < reps; ++i) flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, kt, nullptr);
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("bench (%lld,%lld,%lld,%lld) %s: %d back-to-back launches %.4f ms each -> %.1f TFLOP/s (sustained)\n",
+           (long long)B, (long long)H, (long long)N, (long long)d, flash_kernel_type_name(kt), reps, ms / reps,
+           flops / (ms / reps) * 1e-9);
+  }
   printf("bench (%lld,%lld,%lld,%lld) %s: median %.4f ms  min %.4f ms  -> %.1f TFLOP/s (median), %.1f (best)\n",
          (long long)B, (long long)H, (long long)N, (long long)d, flash_kernel_type_name(kt), med, mn,
          flops / med * 1e-9, flops / mn * 1e-9);

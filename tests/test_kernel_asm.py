@@ -3,8 +3,11 @@ not promise.  The MFMAs are issued from inline asm, so the compiler pads no haza
 free to park their operands in the other register file; these checks read the device assembly.
 
   * no kernel spills to scratch;
-  * in the tuned kernels' main loops no value moves between the VGPR and AGPR files (a
-    v_accvgpr_write placed right in front of an unpadded MFMA would be read too early);
+  * in the hot path of the tuned kernels' main loops (header to back edge; the rare rescale blocks are
+    laid out behind the back edge) no value moves between the VGPR and AGPR files (a v_accvgpr_write
+    placed right in front of an unpadded MFMA would be read too early, a v_accvgpr_read right behind
+    one reads a result that is not there yet);
+  * no MFMA result is touched by anything but a chained MFMA before its result latency is over;
   * the main loops hold exactly the expected number of MFMAs per unrolled tile triple;
   * dynamic LDS stays within the 160 KiB of a CU.
 """
@@ -30,6 +33,8 @@ def asm_text():
 def kernels(asm_text):
     """name -> list of instruction lines (labels kept, comments and directives dropped)."""
     out = {}
+    # a nested loop's header annotation sits on a comment line of its own: pull it up onto the label
+    asm_text = re.sub(r"^(\.LBB\d+_\d+:[^\n]*)\n\s*;\s*=>\s*This", r"\1 =>This", asm_text, flags=re.M)
     for m in re.finditer(r"^(_ZN9flash_hip\S*attn_fwd_kernel[^:\s]*):[^\n]*\n(.*?)^\s*s_endpgm", asm_text, re.S | re.M):
         body = [l.strip() for l in m.group(2).split("\n")]
         out[m.group(1)] = [l for l in body if l and not l.startswith(";") and not l.startswith(".") or l.startswith(".LBB")]
@@ -41,7 +46,7 @@ def main_loop(lines, min_mfma=90):
     tile group; the tail loops with run-time ring slots hold a single tile)."""
     best = None
     for i, l in enumerate(lines):
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        m = re.match(r"^(\.LBB\d+_\d+):.*Loop Header", l)   # branch targets inside a loop are no loops
         if not m:
             continue
         lab = m.group(1)
@@ -52,6 +57,16 @@ def main_loop(lines, min_mfma=90):
                     best = body
                 break
     return best
+
+
+def hot_path(loop):
+    """The fall-through path of a loop: from its header to the (first) branch back to the header.  The
+    compiler lays the out-of-line blocks of the loop (the rescale path) out behind that branch."""
+    header = loop[0].split(":")[0]
+    for j, l in enumerate(loop):
+        if j and re.search(r"s_(cbranch_\w+|branch)\s+" + re.escape(header) + r"\b", l):
+            return loop[:j + 1]
+    return loop
 
 
 def test_no_kernel_spills(asm_text):
@@ -85,20 +100,23 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
         per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
         loop = main_loop(lines, TUNED[frag][0] - per_step)
         assert loop is not None, f"{name}: main loop not found"
-        n_mfma = sum("v_mfma_f32_16x16x32" in l for l in loop)   # the 4x4x4 row-sum MFMAs come on top
+        hot = hot_path(loop)
+        n_mfma = sum("v_mfma_f32_16x16x32" in l for l in hot)   # the 4x4x4 row-sum MFMAs come on top
         want = "v_mfma_f32_16x16x32_bf16" if "bf16_out" in name else "v_mfma_f32_16x16x32_f16"
         assert all(want in l for l in lines if "v_mfma_f32_16x16x32" in l), f"{name}: mixed operand kinds"
         assert n_mfma in (TUNED[frag][0], TUNED[frag][0] - per_step), (name, n_mfma)
-        if "m16p" in frag:
-            # the cold rescale blocks of the persistent kernels are laid out inside the loop's address
-            # range, so a textual scan cannot tell them from the hot path; the operand hazard scan below
-            # covers them
-            continue
-        moves = [l for l in loop if l.startswith("v_accvgpr_")]
+        moves = [l for l in hot if l.startswith("v_accvgpr_")]
         assert not moves, f"{name}: {len(moves)} VGPR<->AGPR moves in the main loop, e.g. {moves[:3]}"
-        assert not any("scratch_" in l or "buffer_store" in l for l in loop), name
+        assert not any("scratch_" in l or "buffer_store" in l for l in hot), name
         # one barrier per tile iteration
-        assert sum(l.startswith("s_barrier") for l in loop) in (TUNED[frag][1], TUNED[frag][1] - 1), name
+        assert sum(l.startswith("s_barrier") for l in hot) in (TUNED[frag][1], TUNED[frag][1] - 1), name
+        # the row sums stay in their fixed accumulation registers, right behind O^T and Q
+        d = 128 if "Li128E" in name else 64
+        base = 192 if d == 128 else 96
+        for l in hot:
+            if "v_mfma_f32_4x4x4" in l:
+                dst = l.split(None, 1)[1].split(",")[0].strip()
+                assert dst in {f"a[{base + 4 * q}:{base + 4 * q + 3}]" for q in range(4)}, (name, l)
 
 
 def _acc_regs(operand_text):
@@ -128,6 +146,48 @@ def test_every_unpadded_mfma_is_clear_of_accvgpr_writes(asm_text):
                 if p.startswith("v_accvgpr_write"):
                     written = _acc_regs(p.split(None, 1)[1].split(",")[0])
                     assert not (written & used), (name, prev, l)
+
+
+def test_no_mfma_result_is_touched_before_its_latency_is_over(asm_text):
+    """The other direction: the first instruction that is not a chained MFMA and names a register an
+    MFMA writes must come at least passes + 3 wait states behind it (16x16x32: 11, 32x32x16: 19,
+    4x4x4: 5), everywhere in every attention kernel.  The checker itself is exercised on a made-up
+    sequence first."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("mfma_hazards", os.path.join(ROOT, "tools", "mfma_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    early = ["v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], a[0:3], v[0:3]", "v_add_f32 v20, v21, v22", "s_nop 3",
+             "v_exp_f32_e32 v30, v1"]
+    assert [(w, n) for _, _, w, n in mod.result_hazards(early)] == [(5, 11)]
+    late = early[:1] + ["v_add_f32 v20, v21, v22"] * 11 + early[-1:]
+    assert mod.result_hazards(late) == []
+    as_operand = early[:1] + ["v_mfma_f32_4x4x4_16b_f16 a[0:3], v[0:1], v[4:5], a[0:3]"]
+    assert len(mod.result_hazards(as_operand)) == 1
+    names = 0
+    for name, lines in mod.kernels(asm_text).items():
+        names += 1
+        found = mod.result_hazards(lines)
+        assert not found, (name, found[:4])
+    assert names >= 16
+
+
+def test_lds_dma_base_register_is_set_and_used_undisturbed(asm_text):
+    """Every global->LDS load takes its LDS base from M0, which the kernels write themselves from inline
+    asm: between that write and the load there must be at least one wait state and no other write of M0
+    (the compiler does not know the register is live there)."""
+    for name, lines in kernels(asm_text).items():
+        ins = [l for l in lines if not l.startswith(".LBB")]
+        loads = [i for i, l in enumerate(ins) if l.startswith("buffer_load") and l.rstrip().endswith("lds")]
+        if "m16" in name or "Lb0" not in name:
+            assert loads, name
+        for i in loads:
+            j = i - 1
+            while j >= 0 and not re.match(r"s_\w+\s+m0\b", ins[j]):
+                assert "m0" not in ins[j].split(None, 1)[0], (name, ins[j])
+                j -= 1
+            assert j >= 0 and i - j >= 2 and i - j <= 12, (name, ins[max(0, i - 6):i + 1])
 
 
 def test_no_mfma_reads_a_register_written_just_before_it(asm_text):

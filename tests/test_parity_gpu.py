@@ -176,12 +176,11 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
     """Scores with a standard deviation of ~90 in exp2 units (|q.k|/sqrt(d) of several hundred): the
     exp2 domain must stay finite and the reference updates must keep up.
 
-    The kernel multiplies Q by softmax_scale*log2(e) and rounds it to fp16 once, a perturbation of Q
-    below one fp16 ulp.  Its effect on a score is ~1.4e-4 times the score spread: invisible for
-    ordinary data (every other test compares against the unperturbed oracle), but at this spread
-    the softmax is an argmax whose near-ties flip under any sub-ulp change of the inputs.  So the
-    2e-3 bar is checked here against the oracle evaluated on the same pre-scaled Q; against the
-    unperturbed oracle only rows whose two largest weights are comparable may differ, and by little."""
+    Q reaches the matrix cores exactly (only the power-of-two part of the scale is applied to it), so the
+    result is compared with the unperturbed oracle, evaluated in float64.  At this spread the softmax is
+    an argmax whose near-ties amplify the fp32 rounding of the scores themselves (one part in 10^7 of a
+    score of several hundred moves a weight by 10^-4), so a small share of rows may sit just above the
+    bar; none may be far off."""
     B, H, N = 1, 1, 384
     for d in (64, 128):
         rng = np.random.default_rng(11 + d)
@@ -191,13 +190,10 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
         q, k, v = (oracle.round_f16(x) for x in (q, k, v))
         o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float16)
         assert np.isfinite(o).all()
-        c = np.float32(1.0 / np.sqrt(d)) * np.float32(1.44269504088896340736)
-        q_pre = oracle.round_f16(q * c)                      # what the kernel feeds the matrix cores
-        q_equiv = (q_pre / c).astype(np.float32)             # the Q that gives exactly those scores
-        assert_close(o, oracle.attn_naive(q_equiv, k, v), f"large scores d={d}, pre-scaled Q")
-        err_rows = np.abs(o - oracle.attn_naive(q, k, v)).max(axis=-1)
-        assert (err_rows > ATOL).mean() <= 0.3 and err_rows.max() <= 0.1, (
-            f"d={d}: {(err_rows > ATOL).mean():.2f} of the rows off, max {err_rows.max():.3e}")
+        err_rows = np.abs(o - oracle.attn_numpy(q, k, v)).max(axis=-1)
+        print(f"large scores d={d}: {(err_rows > ATOL).mean():.3f} of the rows above {ATOL}, max {err_rows.max():.3e}")
+        assert (err_rows > ATOL).mean() <= 0.02 and err_rows.max() <= 1e-2, (
+            f"d={d}: {(err_rows > ATOL).mean():.3f} of the rows off, max {err_rows.max():.3e}")
 
 
 # ---- full-size configurations: size-independent properties + sampled heads vs the oracle ----------
@@ -248,10 +244,11 @@ def test_full_size_properties(fa, oracle, torch_gpu, shape):
     assert float((o2.float() - of).abs().max()) <= ATOL
 
 
-# The long end of the sequence sweep and the per-GPU shard of the 8-GPU configuration: 1.6 GB and 0.8 GB
-# per tensor, so the last heads sit beyond byte offset 2^31 (the reference's 32-bit qkv_offset,
-# flash/kernel_mma_qreg.cuh:34, would wrap there).  Sampled heads against the CPU oracle.
-LONG = [(4, 96, 8192, 128), (4, 96, 16384, 128), (8, 96, 4096, 128)]
+# The long end of the sequence sweep (0.8 and 1.6 GB per tensor), the per-GPU shard of the 8-GPU
+# configuration, and that configuration whole on one GPU: (64, 96, 4096, 128) is 3.2 G elements per
+# tensor, so the last heads sit beyond element (and byte) offset 2^31, where the reference's 32-bit
+# qkv_offset (flash/kernel_mma_qreg.cuh:34) would wrap.  Sampled heads against the CPU oracle.
+LONG = [(4, 96, 8192, 128), (4, 96, 16384, 128), (8, 96, 4096, 128), (64, 96, 4096, 128)]
 
 
 @pytest.mark.parametrize("shape", LONG, ids=str)
@@ -264,7 +261,8 @@ def test_long_sequences_and_shard_sampled_heads(fa, oracle, torch_gpu, shape):
         for b in range(B):
             t[b] = torch.randn((H, N, d), device="cuda:0", generator=gen).half()
     o = fa.forward(q, k, v, fa.KernelType.mma_qreg_async)
-    assert (B * H - 1) * N * d * 2 >= 2 ** 31   # the last head really is past the 32-bit range
+    if B == 64:
+        assert (B * H - 1) * N * d >= 2 ** 31   # the last head really is past the 32-bit range
     for (b, h) in [(0, 0), (B // 2, H // 3), (B - 1, H - 1)]:
         qs, ks, vs = (x[b:b + 1, h:h + 1].float().cpu().numpy() for x in (q, k, v))
         ref = oracle.attn_naive(qs, ks, vs)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""List MFMAs in a gfx950 assembly dump whose source registers are written by one of the few
-instructions right before them (the compiler pads nothing for MFMAs issued from inline asm).
+"""Audit of the hand-issued matrix instructions in a gfx950 assembly dump (the compiler pads nothing for
+MFMAs issued from inline asm), in both directions:
+  * MFMAs whose source registers are written by one of the few instructions right before them;
+  * MFMA results that an instruction other than a chained MFMA touches before the result latency is over.
 
     python tools/mfma_hazards.py build/flash_hip.s [kernel-name-fragment] [window]
 """
@@ -47,6 +49,59 @@ def hazards(lines, window=2):
     return found
 
 
+# Wait states a matrix instruction's result needs before anything but another matrix instruction's
+# accumulator input may touch it (CDNA3/CDNA4 ISA, "XDL write VGPR -> VALU read/write, memory/LDS read":
+# passes + 3 on gfx950), by the pass count of the shapes the kernels use.
+RESULT_WAIT = {"v_mfma_f32_16x16x32": 8 + 3, "v_mfma_f32_32x32x16": 16 + 3, "v_mfma_f32_4x4x4": 2 + 3}
+
+
+def result_hazards(lines, follow=40):
+    """MFMA destination -> first later instruction that is not an MFMA and names one of its registers:
+    list of (mfma, reader, wait states between, wait states required) where too few lie between.
+    Counted as the hardware's sequencer does: every instruction is one wait state, `s_nop N` is N + 1;
+    an MFMA in between counts one (it occupies more, so this is the pessimistic reading).  The scan
+    follows the text forward through fall-through labels and stops at an unconditional branch, at the
+    end of the kernel or after `follow` instructions."""
+    ins = [l for l in lines]
+    found = []
+    for i, l in enumerate(ins):
+        if not l.startswith("v_mfma"):
+            continue
+        need = next((w for k, w in RESULT_WAIT.items() if l.startswith(k)), None)
+        if need is None:
+            continue
+        dst = reg_set(l.split(None, 1)[1].split(",")[0])
+        waited = 0
+        seen = 0
+        for p in ins[i + 1:]:
+            if p.startswith(".LBB"):
+                continue
+            if p.startswith(("s_branch", "s_endpgm", "s_setpc")):
+                break
+            if p.startswith("s_nop"):
+                waited += int(p.split()[1]) + 1
+                continue
+            if waited >= need or seen >= follow:
+                break
+            seen += 1
+            touched = reg_set(p.split(None, 1)[1]) if " " in p else set()
+            if touched & dst:
+                if p.startswith("v_mfma"):
+                    # accumulator chaining (srcC / vDst of the next matrix instruction) is interlocked;
+                    # a result used as an A or B operand is not
+                    ops = p.split(None, 1)[1].split(",")
+                    ab = set()
+                    for o in ops[1:3]:
+                        ab |= reg_set(o)
+                    if ab & dst:
+                        found.append((l, p, waited, need))
+                    break
+                found.append((l, p, waited, need))
+                break
+            waited += 1
+    return found
+
+
 def kernels(asm_text):
     out = {}
     for m in re.finditer(r"^(_ZN9flash_hip\S*attn_fwd_kernel[^:\s]*):[^\n]*\n(.*?)^\s*s_endpgm", asm_text, re.S | re.M):
@@ -66,3 +121,7 @@ if __name__ == "__main__":
         print(name, ":", len(h), "suspicious MFMAs of", sum("v_mfma" in l for l in lines))
         for p, l in h[:12]:
             print("   ", p, " -> ", l)
+        r = result_hazards(lines)
+        print("   results read too early:", len(r))
+        for m, p, w, need in r[:12]:
+            print("   ", m, " -> ", p, f"  ({w} of {need} wait states)")

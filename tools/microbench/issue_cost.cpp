@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256, 1) void k(const f16x8* in, float* out, long lo
         if constexpr (KIND == FILL_MAX3) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(f[x]) : "v"(f[y]), "v"(f[z]), "v"(f[(x + 3) & 15]));
         if constexpr (KIND == FILL_WAIT) asm volatile("s_waitcnt lgkmcnt(8)");
         if constexpr (KIND == FILL_NOP) asm volatile("s_nop 0");
+        if constexpr (KIND == FILL_PKMULF32) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(*(double*)&f[(2 * x) & 14]) : "v"(*(double*)&f[(2 * y) & 14]), "v"(*(double*)&f[(2 * z) & 14]));
         if constexpr (KIND == FILL_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(f[x]) : "v"(f[y]));
         if constexpr (KIND == FILL_PKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[x & 7]) : "v"(f[y]), "v"(f[z]));
         if constexpr (KIND == FILL_EXPH) asm volatile("v_exp_f16 %0, %1" : "=v"(u[x & 7]) : "v"(u[y & 7]));
@@ -131,6 +132,13 @@ int main() {
   run<FILL_ADD, 4>(in, out, cyc, "v_add_f32");
   run<FILL_ADD, 5>(in, out, cyc, "v_add_f32");
   run<FILL_ADD, 6>(in, out, cyc, "v_add_f32");
+  run<FILL_PKMULF32, 4>(in, out, cyc, "v_pk_mul_f32");
+  run<FILL_PKMULF32, 8>(in, out, cyc, "v_pk_mul_f32");
+  run<FILL_FMA, 8>(in, out, cyc, "v_fma_f32");
+  run<FILL_NOP, 6>(in, out, cyc, "s_nop 0");
+  run<FILL_NOP, 12>(in, out, cyc, "s_nop 0");
+  run<FILL_EXP, 4>(in, out, cyc, "v_exp_f32");
+  run<FILL_MAX3, 6>(in, out, cyc, "v_max3_f32");
   run<FILL_PKRTZ, 12>(in, out, cyc, "v_cvt_pkrtz_f16_f32");
   run<FILL_CVT, 6>(in, out, cyc, "v_cvt_pk_f16_f32");
   run<FILL_EXPH, 8>(in, out, cyc, "v_exp_f16");
