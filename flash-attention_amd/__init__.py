@@ -67,7 +67,7 @@ class LaunchInfo:
 
 # every symbol include/flash_hip.h declares
 ABI_SYMBOLS = (
-    "flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_ws",
+    "flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_ws", "flash_fwd_f32_static",
     "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
     "flash_fwd_query_entry",
     "flash_kernel_type_name",
@@ -92,7 +92,7 @@ def lib() -> ctypes.CDLL:
 
     L = ctypes.CDLL(LIB_PATH)
     i64, vp = ctypes.c_int64, ctypes.c_void_p
-    for name in ("flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32"):
+    for name in ("flash_fwd_f16", "flash_fwd_bf16", "flash_fwd_f32", "flash_fwd_f32_static"):
         fn = getattr(L, name)
         fn.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, ctypes.c_float, ctypes.c_int, vp]
         fn.restype = ctypes.c_int

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -21,10 +22,17 @@
 #include <vector>
 #endif
 
+// Built-in scratch of flash_fwd_f32_static: room for the three fp16 copies of Q, K and V.  A device
+// array, so every GPU that loads this library holds 48 MiB for it until the process ends.  Host code
+// reaches it only through the address hipGetSymbolAddress returns (static_scratch_ptr below).
+constexpr int64_t kStaticScratchBytes = FLASH_HIP_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 namespace {
 
 using namespace flash_hip;
 
+int static_scratch_ptr(void** out);
 int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
                         float softmax_scale, int kernel_type, void* workspace, int64_t workspace_bytes,
                         void* hip_stream);
@@ -295,6 +303,30 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   return launch_fast<float>(prm, plan, N, stream);
 }
 
+// Address of this device's copy of the built-in scratch array.  Every GPU the library runs on holds
+// its own copy at its own address; the array's name is only a host-side handle for
+// hipGetSymbolAddress and is never used as a pointer.  Resolved once per device, with that device
+// current, on the first call that needs it there.
+constexpr int kMaxDevices = 64;
+std::atomic<void*> g_scratch_ptr[kMaxDevices];
+
+int static_scratch_ptr(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "hipGetDevice failed: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= kMaxDevices)
+    return fail(FLASH_HIP_ERR_RUNTIME, "device ordinal %d is outside the %d the built-in scratch supports", dev, kMaxDevices);
+  void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!ptr) {
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+      return fail(FLASH_HIP_ERR_RUNTIME, "hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+    g_scratch_ptr[dev].store(ptr, std::memory_order_release);  // racing first calls resolve the same address
+  }
+  *out = ptr;
+  return FLASH_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -333,6 +365,25 @@ int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d
 int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
                      float softmax_scale, int kernel_type, void* workspace, int64_t workspace_bytes, void* hip_stream) {
   return forward_f32_scratch(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, workspace, workspace_bytes, hip_stream);
+}
+
+int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N,
+                         int64_t d, float softmax_scale, int kernel_type, void* hip_stream) {
+  Plan plan;
+  int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
+  if (rc != FLASH_HIP_OK) return rc;
+  const int64_t need = plan.fast ? kCastTensors * ws_tensor_bytes(B, H, N, d) : 0;
+  if (need > kStaticScratchBytes)
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT,
+                "flash_fwd_f32_static: this shape needs %lld bytes of scratch, the built-in buffer holds %lld "
+                "(B*H*N*d <= %lld elements); use flash_fwd_f32_ws with caller memory",
+                (long long)need, (long long)kStaticScratchBytes, (long long)(kStaticScratchBytes / kCastTensors / 2));
+  void* ws = nullptr;
+  if (need > 0) {
+    rc = static_scratch_ptr(&ws);
+    if (rc != FLASH_HIP_OK) return rc;
+  }
+  return forward_f32_scratch(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, ws, need, hip_stream);
 }
 
 int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, flash_launch_info* out) {

@@ -140,6 +140,28 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
                      float softmax_scale, int kernel_type,
                      void* workspace, int64_t workspace_bytes, void* hip_stream);
 
+/*
+ * flash_fwd_f32_ws without the workspace argument, for callers that cannot allocate device memory
+ * or hand any over: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  No counterpart in the reference.  The scratch for the fp16 copies of Q, K and V is a
+ * device array built into the library, FLASH_HIP_STATIC_SCRATCH_BYTES (48 MiB) on every GPU the
+ * library runs on, held until the process ends.  The call allocates and frees nothing (no hipMalloc,
+ * no allocating library routine); it enqueues the same kernels as flash_fwd_f32_ws on `hip_stream`
+ * and gives bit-identical results.
+ * Limit: shapes whose workspace (flash_fwd_f32_workspace_bytes) exceeds the built-in buffer, i.e.
+ * B*H*N*d > 8 Mi elements, are rejected with INVALID_ARGUMENT and a text naming both sizes; use
+ * flash_fwd_f32_ws for those.  Shapes that need no workspace (d % 8 != 0, tensors off a 16-byte
+ * boundary) behave like flash_fwd_f32.
+ * All calls on one GPU share that GPU's buffer: calls that may overlap in time on one GPU (different
+ * streams, different threads) race on it and must be serialised by the caller.  Nothing in the
+ * buffer needs clearing between calls: every byte a call reads was written by the same call.
+ * The buffer's address is looked up once per device, on the first call made with that device current.
+ */
+#define FLASH_HIP_STATIC_SCRATCH_BYTES (48ll << 20)
+int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o,
+                         int64_t B, int64_t H, int64_t N, int64_t d,
+                         float softmax_scale, int kernel_type, void* hip_stream);
+
 /* Workspace flash_fwd_f32_ws uses for this shape: 3 fp16 copies of B*H*N*d elements when d % 8 == 0,
  * 0 when the shape has no fast path, -1 (and an error text) when the shape or kernel type is
  * rejected.  Does not touch the GPU. */

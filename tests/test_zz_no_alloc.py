@@ -1,0 +1,67 @@
+"""GPU: the allocation-free fp32 entry point (flash_fwd_f32_static: scratch in a device array built
+into the library) against flash_fwd_f32_ws with caller scratch, through the C ABI.  Both enqueue the
+same kernels, so the outputs must be bit-identical; checked on two calls in a row, the second on a
+smaller input, and against the CPU oracle at the usual bar."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _call(L, torch, name, tensors, shape, ws=None):
+    B, H, N, d = shape
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    args = [t.data_ptr() for t in tensors] + [B, H, N, d, 1.0 / np.sqrt(d), 11]
+    if name == "flash_fwd_f32_ws":
+        rc = L.flash_fwd_f32_ws(*args, ws.data_ptr(), ws.numel(), stream)
+    else:
+        rc = L.flash_fwd_f32_static(*args, stream)
+    return rc
+
+
+def test_static_scratch_entry_matches_workspace_entry(fa, oracle):
+    import torch
+
+    assert torch.cuda.is_available()
+    L = fa.lib()
+    rng = np.random.default_rng(2024)
+    # second call smaller than the first: stale contents of the shared buffer must not leak into it
+    for shape in ((2, 4, 1024, 128), (1, 3, 300, 64)):
+        B, H, N, d = shape
+        host = [rng.standard_normal(shape).astype(np.float32) * np.float32(1.1) for _ in range(3)]
+        q, k, v = (torch.from_numpy(x).to("cuda:0") for x in host)
+        need = L.flash_fwd_f32_workspace_bytes(B, H, N, d, 11)
+        assert 0 < need <= 48 << 20
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda:0")
+        o_ws = torch.full_like(q, float("nan"))
+        o_st = torch.full_like(q, float("nan"))
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info()[0]
+        assert _call(L, torch, "flash_fwd_f32_static", (q, k, v, o_st), shape) == 0, L.flash_hip_last_error()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free_before or shape[2] == 1024   # (first call may load code)
+        assert _call(L, torch, "flash_fwd_f32_ws", (q, k, v, o_ws), shape, ws) == 0, L.flash_hip_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(o_st, o_ws), f"{shape}: static-scratch output differs from the workspace entry"
+        ref = oracle.attn_naive(*(oracle.round_f16(x) for x in host))
+        assert_close(o_st.cpu().numpy(), ref, f"{shape} static scratch")
+
+
+def test_static_scratch_entry_rejects_what_does_not_fit(fa):
+    import torch
+
+    L = fa.lib()
+    t = torch.zeros(16, device="cuda:0")
+    # (1, 16, 4096, 128) is exactly the limit (8 Mi elements); one more head is over it
+    over = (1, 17, 4096, 128)
+    rc = L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), *over, 0.1, 11, None)
+    assert rc == -1
+    msg = L.flash_hip_last_error().decode()
+    assert "flash_fwd_f32_static" in msg and str(48 << 20) in msg and "flash_fwd_f32_ws" in msg
+    assert L.flash_fwd_f32_workspace_bytes(1, 16, 4096, 128, 11) == 48 << 20
+    # errors of the plain entry points are kept
+    assert L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 1, 64, 200, 0.1, 11, None) == -2
