@@ -141,11 +141,15 @@ constexpr int kPvAccumulate = 0;  // O += V^T P^T
 constexpr int kPvSkip = 1;        // nothing: the very first step of an item has no P yet
 constexpr int kPvFirst = 2;       // O  = V^T P^T (first product of an item)
 
-// Row sums on the matrix pipe: v_mfma_f32_4x4x4_16b_f16 computes, for 16 independent 4x4 blocks,
-// D[i][j] = sum_k A[i][k] B[k][j] + C[i][j], where a lane holds the four k-values of one column j of B
-// and gets D[0..3][j] in its four result registers.  With A = all ones every D[i][j] of a lane is the
-// sum of the lane's own four fp16 values, accumulated in fp32: one 2-pass MFMA replaces the vector adds
-// of four probabilities, exactly.
+// Row sums on the matrix pipe: one more 16x16x32 product per query block and 32-key block, with an A
+// operand whose row 0 is all ones and whose other rows are zero.  Row 0 of the result tile is then the
+// sum over the block's 32 keys of every query's probabilities, accumulated in fp32 (exactly: the
+// addends are the fp16 values the P V product uses); rows 1..15 stay zero.  In the tile layout row 0
+// is register 0 of the lanes with g = 0, so the sum of a query sits in one of its four lanes and the
+// other three hold zeros: the four-lane sum of the epilogue collects it unchanged.
+// (v_mfma_f32_4x4x4_16b_f16 with an all-ones A sums a lane's own four values and looks cheaper, 2 passes
+// against 4, but it holds up the issue of the wave's next instruction for 13 cycles against 8, and two of
+// them are needed per block.)
 typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 // The row sums of query block q live in fixed accumulation registers, right behind O^T and Q
 // (D = 128: a[192 + 4q ..], D = 64: a[96 + 4q ..]), named in the operand constraints.  Left to itself
@@ -170,11 +174,11 @@ typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
   }
 // `q` must be a compile-time constant at the call site after inlining (the other cases fold away).
 template <int D, int EK = kF16>
-__device__ __forceinline__ void mfma_rowsum(f32x4& acc, int q, const f16x4v& ones, const f16x4v& p4) {
+__device__ __forceinline__ void mfma_rowsum(f32x4& acc, int q, const f16x8& ones_row, const f16x8& p) {
   if constexpr (EK == kBF16) {
-    FLASH_LSUM_SWITCH(q, "v_mfma_f32_4x4x4_16b_bf16 %0, %1, %2, %0", "v"(ones), "v"(p4))
+    FLASH_LSUM_SWITCH(q, "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0", "v"(ones_row), "v"(p))
   } else {
-    FLASH_LSUM_SWITCH(q, "v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0", "v"(ones), "v"(p4))
+    FLASH_LSUM_SWITCH(q, "v_mfma_f32_16x16x32_f16 %0, %1, %2, %0", "v"(ones_row), "v"(p))
   }
 }
 // The accumulation registers of query block q's row sum, tied to their place (no instruction).
@@ -328,27 +332,20 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
 
   // exp(j), software-pipelined over the slots.  Element g = 8q + e: key block e / 4, register e % 4.
   float t_exp = 0.f, t_exp_prev = 0.f;
-  f16x4v ones4 = __builtin_bit_cast(f16x4v, u32x2{kOnes2<EK>, kOnes2<EK>});
-  asm volatile("" : "+v"(ones4));
+  // A operand of the row-sum product: row n = lane & 15 of the 16 x 32 block, ones in row 0 only
+  const uint32_t one2 = (lane & 15) == 0 ? kOnes2<EK> : 0u;
+  f16x8 ones_row = __builtin_bit_cast(f16x8, u32x4{one2, one2, one2, one2});
+  asm volatile("" : "+v"(ones_row));
   auto pin = [](f16x2& x) __attribute__((always_inline)) {
     uint32_t w = __builtin_bit_cast(uint32_t, x);
     asm volatile("" : "+v"(w));
     x = __builtin_bit_cast(f16x2, w);
   };
-  // row sum of the four probabilities packed two elements ago: half `hf` of query block q's fragment
-  auto group_add = [&](int group) __attribute__((always_inline)) {
-    const int q = group / 2, hf = group % 2;
-    f16x4v p4;
-    if (hf == 0) {
-      p4 = __builtin_shufflevector(p_cur[q], p_cur[q], 0, 1, 2, 3);
-    } else {
-      p4 = __builtin_shufflevector(p_cur[q], p_cur[q], 4, 5, 6, 7);
-    }
-    mfma_rowsum<D, EK>(lsum[q], q, ones4, p4);
-  };
+  // row sum of query block q's fragment, whose last pair was packed two elements ago
+  auto group_add = [&](int q) __attribute__((always_inline)) { mfma_rowsum<D, EK>(lsum[q], q, ones_row, p_cur[q]); };
   auto finish = [&](int g) __attribute__((always_inline)) {
     const int q = g / 8, e = g % 8;
-    if ((g & 3) == 1 && g >= 5) group_add(g / 4 - 1);
+    if ((g & 7) == 1 && g >= 9) group_add(g / 8 - 1);
     if ((g & 1) != 0) {
       f16x2 w = __builtin_bit_cast(f16x2, pack2<EK>(t_exp_prev, t_exp));
       pin(w);
@@ -475,13 +472,13 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     vote = pending;
     asm volatile("s_nop 1" ::: "memory");
   }
-  group_add(ELEMS / 4 - 1);
+  group_add(kQ16 - 1);
 }
 
 // Wait states before the row sums are read by anything but the MFMA that accumulates them.
 template <int D>
 __device__ __forceinline__ void drain_lsum(f32x4 (&lsum)[kQ16]) {
-  asm volatile("s_nop 7" ::: "memory");
+  asm volatile("s_nop 11" ::: "memory");  // result latency of the row-sum product: 8 passes + 3
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) pin_lsum<D>(lsum[q], q);
 }
@@ -773,7 +770,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   float mx_all = 0.f;  // in-lane maximum of the block whose scores were computed last
   uint64_t vote = 0;   // see pipeline_step / step_end
   f32x4 bias[kQ16];
-  f32x4 lsum[kQ16];  // row sums, every register of a lane holds the same partial sum (see mfma_rowsum)
+  f32x4 lsum[kQ16];  // row sums: register 0 of the lanes with g = 0, zeros elsewhere (see mfma_rowsum)
   uint64_t pending = 0;
 #pragma unroll
   for (int q = 0; q < kQ16; ++q) {

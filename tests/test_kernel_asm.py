@@ -83,10 +83,10 @@ def test_no_kernel_spills(asm_text):
 
 TUNED = {
     # kernel-name fragment -> (MFMAs in the unrolled main loop, barriers in it); 16x16x32 MFMAs
-    "attn_fwd_kernel_m16ILi128E": (6 * 64, 3),    # d=128 tile: 32 QK + 32 PV per step, 3 tiles
-    "attn_fwd_kernel_m16ILi64E": (6 * 32, 3),     # d=64 tile: 16 QK + 16 PV per step
-    "attn_fwd_kernel_m16pILi128E": (8 * 64, 4),   # persistent variant: 4 tiles per loop trip (the compiler
-    "attn_fwd_kernel_m16pILi64E": (8 * 32, 4),    # may rotate one step of them out of the loop)
+    "attn_fwd_kernel_m16ILi128E": (6 * 68, 3),    # d=128 tile: 32 QK + 32 PV + 4 row sums per step, 3 tiles
+    "attn_fwd_kernel_m16ILi64E": (6 * 36, 3),     # d=64 tile: 16 QK + 16 PV + 4 row sums per step
+    "attn_fwd_kernel_m16pILi128E": (8 * 68, 4),   # persistent variant: 4 tiles per loop trip (the compiler
+    "attn_fwd_kernel_m16pILi64E": (8 * 36, 4),    # may rotate one step of them out of the loop)
 }
 
 
@@ -101,7 +101,7 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
         loop = main_loop(lines, TUNED[frag][0] - per_step)
         assert loop is not None, f"{name}: main loop not found"
         hot = hot_path(loop)
-        n_mfma = sum("v_mfma_f32_16x16x32" in l for l in hot)   # the 4x4x4 row-sum MFMAs come on top
+        n_mfma = sum("v_mfma_f32_16x16x32" in l for l in hot)
         want = "v_mfma_f32_16x16x32_bf16" if "bf16_out" in name else "v_mfma_f32_16x16x32_f16"
         assert all(want in l for l in lines if "v_mfma_f32_16x16x32" in l), f"{name}: mixed operand kinds"
         assert n_mfma in (TUNED[frag][0], TUNED[frag][0] - per_step), (name, n_mfma)
@@ -113,10 +113,15 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
         # the row sums stay in their fixed accumulation registers, right behind O^T and Q
         d = 128 if "Li128E" in name else 64
         base = 192 if d == 128 else 96
+        sums = {f"a[{base + 4 * q}:{base + 4 * q + 3}]" for q in range(4)}
+        n_sum = 0
         for l in hot:
-            if "v_mfma_f32_4x4x4" in l:
-                dst = l.split(None, 1)[1].split(",")[0].strip()
-                assert dst in {f"a[{base + 4 * q}:{base + 4 * q + 3}]" for q in range(4)}, (name, l)
+            dst = l.split(None, 1)[1].split(",")[0].strip() if l.startswith("v_mfma") else ""
+            if dst.startswith("a["):
+                lo = int(dst[2:].split(":")[0])
+                assert lo + 3 < base or dst in sums, (name, l)   # O^T (below the row sums), or a row sum in its place
+                n_sum += dst in sums
+        assert n_sum in (4 * 2 * TUNED[frag][1], 4 * (2 * TUNED[frag][1] - 1)), (name, n_sum)
 
 
 def _acc_regs(operand_text):

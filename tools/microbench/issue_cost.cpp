@@ -29,8 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FILL_MIX_TR 17     // 4 v_add + NF ds_read_b64_tr_b16 (8-byte stride)
 #define FILL_CMP 18
 #define FILL_PERM 19
+#define FILL_MFMA4 20   // v_mfma_f32_4x4x4_16b_f16 on an accumulator of its own
+#define FILL_MUL 21
 
-template <int KIND, int NF>
+template <int KIND, int NF, int BASE = 0>
 __global__ __launch_bounds__(256, 1) void k(const f16x8* in, float* out, long long* cyc, int iters) {
   __shared__ __attribute__((aligned(16))) char lds[32768];
   const int tid = threadIdx.x + blockIdx.x * 256;
@@ -48,6 +50,12 @@ __global__ __launch_bounds__(256, 1) void k(const f16x8* in, float* out, long lo
   f16x8 ld[4] = {a[0], a[1], a[2], a[3]};
   const unsigned lds_addr = (unsigned)(size_t)lds + (threadIdx.x & 63) * 16;
   const unsigned lds_addr8 = (unsigned)(size_t)lds + (threadIdx.x & 63) * 8;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+  f32x4 c4[8], r4[4];
+  for (int i = 0; i < 8; ++i) c4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i) r4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f16x4 h4[2] = {{a[0][0], a[0][1], a[0][2], a[0][3]}, {a[1][0], a[1][1], a[1][2], a[1][3]}};
   f32x16 c[8];
   for (int i = 0; i < 8; ++i)
     for (int j = 0; j < 16; ++j) c[i][j] = 0.f;
@@ -55,7 +63,11 @@ __global__ __launch_bounds__(256, 1) void k(const f16x8* in, float* out, long lo
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[m]) : "v"(a[m & 3]), "v"(b[(m >> 1) & 3]));
+      if constexpr (BASE == 0) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[m]) : "v"(a[m & 3]), "v"(b[(m >> 1) & 3]));
+      } else {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c4[m]) : "v"(a[m & 3]), "v"(b[(m >> 1) & 3]));
+      }
       if constexpr (KIND == FILL_MIX_B128 || KIND == FILL_MIX_TR) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -75,6 +87,8 @@ __global__ __launch_bounds__(256, 1) void k(const f16x8* in, float* out, long lo
         if constexpr (KIND == FILL_MAX3) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(f[x]) : "v"(f[y]), "v"(f[z]), "v"(f[(x + 3) & 15]));
         if constexpr (KIND == FILL_WAIT) asm volatile("s_waitcnt lgkmcnt(8)");
         if constexpr (KIND == FILL_NOP) asm volatile("s_nop 0");
+        if constexpr (KIND == FILL_MFMA4) asm volatile("v_mfma_f32_4x4x4_16b_f16 %0, %1, %2, %0" : "+v"(r4[e & 3]) : "v"(h4[0]), "v"(h4[1]));
+        if constexpr (KIND == FILL_MUL) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(f[x]) : "v"(f[y]), "v"(f[z]));
         if constexpr (KIND == FILL_PKMULF32) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(*(double*)&f[(2 * x) & 14]) : "v"(*(double*)&f[(2 * y) & 14]), "v"(*(double*)&f[(2 * z) & 14]));
         if constexpr (KIND == FILL_MOV) asm volatile("v_mov_b32 %0, %1" : "=v"(f[x]) : "v"(f[y]));
         if constexpr (KIND == FILL_PKRTZ) asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(u[x & 7]) : "v"(f[y]), "v"(f[z]));
@@ -94,22 +108,24 @@ __global__ __launch_bounds__(256, 1) void k(const f16x8* in, float* out, long lo
   for (int i = 0; i < 8; ++i)
     for (int j = 0; j < 16; ++j) acc += c[i][j];
   for (int i = 0; i < 16; ++i) acc += f[i];
+  for (int i = 0; i < 8; ++i) acc += c4[i][0] + c4[i][3];
+  for (int i = 0; i < 4; ++i) acc += r4[i][0];
   for (int i = 0; i < 8; ++i) acc += (float)u[i];
   for (int i = 0; i < 4; ++i) acc += (float)ld[i][0];
   out[tid] = acc;
   if ((threadIdx.x & 63) == 0) cyc[tid >> 6] = t1 - t0;
 }
 
-template <int KIND, int NF>
+template <int KIND, int NF, int BASE = 0>
 void run(const f16x8* in, float* out, long long* cyc, const char* name) {
   const int iters = 2000;
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<KIND, NF>), dim3(256), dim3(256), 0, 0, in, out, cyc, iters);
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<KIND, NF, BASE>), dim3(256), dim3(256), 0, 0, in, out, cyc, iters);
   (void)hipDeviceSynchronize();
   std::vector<long long> h(1024);
   (void)hipMemcpy(h.data(), cyc, 1024 * 8, hipMemcpyDeviceToHost);
   std::sort(h.begin(), h.end());
   const double per = (double)h[512] / (iters * 8.0);
-  printf("%-22s NF=%d  cycles/MFMA %.1f   => per filler %.2f (if issue-bound: (cyc-8)/NF)\n", name, NF, per,
+  printf("%s %-22s NF=%d  cycles/MFMA %.1f   => per filler %.2f (if issue-bound: (cyc-8)/NF)\n", BASE ? "[16x16x32]" : "[32x32x16]", name, NF, per,
          NF ? (per - 8.0) / NF : 0.0);
 }
 
@@ -128,6 +144,18 @@ int main() {
   (void)hipMalloc(&out, 256 * 256 * 4);
   (void)hipMalloc(&cyc, 1024 * 8);
   (void)hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  run<FILL_NONE, 0, 1>(in, out, cyc, "none");
+  run<FILL_ADD, 1, 1>(in, out, cyc, "v_add_f32");
+  run<FILL_ADD, 2, 1>(in, out, cyc, "v_add_f32");
+  run<FILL_ADD, 3, 1>(in, out, cyc, "v_add_f32");
+  run<FILL_ADD, 4, 1>(in, out, cyc, "v_add_f32");
+  run<FILL_EXP, 2, 1>(in, out, cyc, "v_exp_f32");
+  run<FILL_MFMA4, 1, 1>(in, out, cyc, "mfma 4x4x4");
+  run<FILL_MFMA4, 2, 1>(in, out, cyc, "mfma 4x4x4");
+  run<FILL_MFMA4, 4, 1>(in, out, cyc, "mfma 4x4x4");
+  run<FILL_MFMA4, 2, 0>(in, out, cyc, "mfma 4x4x4");
+  run<FILL_MFMA4, 6, 0>(in, out, cyc, "mfma 4x4x4");
+  run<FILL_MUL, 6, 0>(in, out, cyc, "v_mul_f32");
   run<FILL_NONE, 0>(in, out, cyc, "none");
   run<FILL_ADD, 4>(in, out, cyc, "v_add_f32");
   run<FILL_ADD, 5>(in, out, cyc, "v_add_f32");
