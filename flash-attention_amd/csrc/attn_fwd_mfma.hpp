@@ -78,11 +78,14 @@ struct FwdParams {
   int d;              // head dim (<= D)
   int nqt;            // query tiles per head = ceil(N / kBr)
   uint32_t total_wg;  // B * H * nqt
-  // softmax_scale * log2(e) = q_scale * s_scale.  q_scale is a power of two: multiplying Q by it is
-  // exact in 16-bit floating point, so the matrix cores see the caller's Q bit for bit (shifted);
-  // s_scale in [1, 2) multiplies the fp32 scores just before the exponential.  (One rounding of
-  // Q * softmax_scale * log2(e) to fp16 would be cheaper by one multiply per score, but it perturbs
-  // every score by 2^-11 relative and was measured to be the largest error term of the kernel by far.)
+  // softmax_scale * log2(e) = q_scale * s_scale.  q_scale multiplies Q before the matrix products and
+  // is a power of two, which is exact in 16-bit floating point; s_scale multiplies the fp32 scores just
+  // before the exponential.  The 16x16x32 kernels keep the reference of a query in fp32 and get
+  // q_scale = 1: Q reaches the matrix cores bit for bit as the caller stored it.  The 32x32x16 kernel
+  // carries the reference through fp16 operands and gets the power of two that brings the scores into
+  // exp2 range (s_scale in [1, 2)).  (One rounding of Q * softmax_scale * log2(e) to fp16 would save
+  // the multiply per score, but it perturbs every score by 2^-11 relative and was measured to be the
+  // largest error term of the kernel by far.)
   float q_scale;
   float s_scale;
   float defer_thr;    // kDeferLog2 / s_scale: the deferral threshold in units of the unscaled scores

@@ -603,21 +603,6 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
   }
 }
 
-// One register of two packed Q values times `sc`, the power-of-two part of softmax_scale * log2(e):
-// exact in both 16-bit formats (only values that land in the subnormal range lose bits, an absolute
-// error below 2^-25).
-//  fp16: one packed multiply by sc in both halves;
-//  bf16: the halves are widened by shifts / masks, multiplied in fp32 and packed by v_cvt_pk_bf16_f32.
-template <int EK>
-__device__ __forceinline__ uint32_t scale_q2(uint32_t x, float sc) {
-  if constexpr (EK == kBF16) {
-    return pack2<kBF16>(__uint_as_float(x << 16) * sc, __uint_as_float(x & 0xFFFF0000u) * sc);
-  } else {
-    const f16x2 s2 = {(f16)sc, (f16)sc};
-    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, x) * s2);
-  }
-}
-
 template <int D, typename TO = f16>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -688,9 +673,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
 
   const int nt = (N + kBc - 1) / kBc;
 
-  // ---- Q fragments, pre-multiplied by softmax_scale * log2(e) ------------------------------------------
-  // The loads are issued before the K/V staging traffic: loads return in order, so the conversion of
-  // Q overlaps the tiles that are still in flight.
+  // ---- Q fragments, as the caller stored them: softmax_scale * log2(e) multiplies the fp32 scores -------
+  // The loads are issued before the K/V staging traffic (loads return in order).
   int qrow[kQ16];
   f16x8 qf[kQ16][kKS];
 #pragma unroll
@@ -710,16 +694,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   // Step 0 multiplies P(-1) = 0 with the second block of "V tile -1" (slot 2): make that finite.
   for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
     *FLASH_LDS_CAST(u32x4, v_ring + 2 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
-  }
-#pragma unroll
-  for (int q = 0; q < kQ16; ++q) {
-#pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) {
-      u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], p.q_scale);
-      qf[q][ks] = __builtin_bit_cast(f16x8, w);
-    }
   }
   f32x4 o[kQ16][kDv16];
 #pragma unroll
@@ -870,8 +844,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
 // the last two tile iterations of an item already stage the first tiles of the next one, so the next
 // item finds K tiles 0, 1 and V tile 0 in LDS.  Its Q is fetched (raw, straight into the
 // accumulation registers that hold Q) while the current item's last P V product and output stores
-// run.  What remains between two items is S(0) of the next item and the conversion of Q; the
-// HBM round trips of a cold prologue are paid once per workgroup instead of once per item.
+// run; the matrix instructions read it there as the caller stored it (the whole softmax scale is
+// applied to the fp32 scores).  What remains between two items is S(0) of the next item; the HBM
+// round trips of a cold prologue are paid once per workgroup instead of once per item.
 constexpr int kRingP = 4;
 
 template <int D>
@@ -991,21 +966,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       }
     }
   };
-  // pre-multiply by softmax_scale * log2(e); the registers come back as accumulation registers
-  auto convert_q = [&]() __attribute__((always_inline)) {
-    const float qs = p.q_scale;
-#pragma unroll
-    for (int q = 0; q < kQ16; ++q) {
-#pragma unroll
-      for (int ks = 0; ks < kKS; ++ks) {
-        u32x4 w = __builtin_bit_cast(u32x4, qf[q][ks]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = scale_q2<EK>(w[j], qs);
-        qf[q][ks] = __builtin_bit_cast(f16x8, w);
-        asm volatile("" : "+a"(qf[q][ks]));
-      }
-    }
-  };
 
   // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
   srd_t k_srd = make_srd((const f16*)p.k + (size_t)head_of(item) * head_elems, head_bytes);
@@ -1019,7 +979,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 1, 1, i);
   const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
   wait_q<0>(qf);
-  convert_q();
   __syncthreads();
 
   f32x4 o[kQ16][kDv16];
@@ -1198,8 +1157,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     if (!has_next) break;
     // the Q loads are older than this item's output stores: wait for everything but those stores
     wait_q<kQ16 * OutStores<TO>::per_block(kDv16)>(qf);
-    convert_q();
-#if defined(FLASH_PHASE_STAMPS)
+  #if defined(FLASH_PHASE_STAMPS)
     acc_pro += stamp_loop - stamp_item;
     acc_loop += stamp_tail - stamp_loop;
     acc_tail += __builtin_amdgcn_s_memtime() - stamp_tail;

@@ -94,9 +94,10 @@ int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool 
 
 
 // Kernel arguments of one call.  The kernels work in the exp2 domain: the softmax scale carries log2(e)
-// and is split into an exact power of two for Q and a residual factor for the scores.
+// and is split into an exact power of two for Q (`scale_q`: the 32x32x16 kernel only, see FwdParams)
+// and the factor that multiplies the fp32 scores.
 FwdParams make_params(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
-                      float softmax_scale, const Plan& plan) {
+                      float softmax_scale, const Plan& plan, bool scale_q) {
   FwdParams prm{};
   prm.q = q;
   prm.k = k;
@@ -110,7 +111,7 @@ FwdParams make_params(const void* q, const void* k, const void* v, void* o, int6
   // overflows fp16 nor needs more than the format's normal range (outside that window c takes the rest)
   const float x = softmax_scale * 1.44269504088896340736f;
   int e = 0;
-  if (x > 0.f && std::isfinite(x)) {
+  if (scale_q && x > 0.f && std::isfinite(x)) {
     (void)std::frexp(x, &e);  // x = m * 2^e, m in [0.5, 1)
     e -= 1;                   // x = (2m) * 2^(e-1)
   }
@@ -252,17 +253,18 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   int rc = make_plan(B, H, N, d, kernel_type, sizeof(T) == 2, &plan);
   if (rc != FLASH_HIP_OK) return rc;
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
-  const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan);
   hipStream_t stream = (hipStream_t)hip_stream;
   if constexpr (sizeof(T) == 2) {
     if (plan.fast && aligned16(q, k, v, o)) {
 #if defined(FLASH_MFMA32)  // comparison builds: the 32x32x16 kernel on the fast path as well
+      const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, true);
       return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
 #else
-      return launch_fast<f16>(prm, plan, N, stream);
+      return launch_fast<f16>(make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, false), plan, N, stream);
 #endif
     }
   }
+  const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, true);
   return plan.tile_d == 64 ? launch<64, T, false>(prm, plan.lds, stream) : launch<128, T, false>(prm, plan.lds, stream);
 }
 
@@ -299,7 +301,7 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, cp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
-  const FwdParams prm = make_params(cp.dst[0], cp.dst[1], cp.dst[2], o, B, H, N, d, softmax_scale, plan);
+  const FwdParams prm = make_params(cp.dst[0], cp.dst[1], cp.dst[2], o, B, H, N, d, softmax_scale, plan, false);
   return launch_fast<float>(prm, plan, N, stream);
 }
 
@@ -352,7 +354,7 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
   if (!aligned16(q, k, v, o))
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "bfloat16 tensors must be 16-byte aligned");
-  const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan);
+  const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, false);
   return launch_fast<m16::bf16_out>(prm, plan, N, (hipStream_t)hip_stream);
 }
 
