@@ -124,7 +124,7 @@ FwdParams make_params(const void* q, const void* k, const void* v, void* o, int6
 
 template <typename Kernel>
 int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16],
-                  uint32_t grid = 0) {
+                  uint32_t grid = 0, uint32_t threads = kThreads) {
   if (grid == 0) grid = prm.total_wg;
   // Above the 64 KiB default a kernel must opt in to its dynamic LDS size (the reference does the
   // same above 48 KiB, launch.cu:134-148).
@@ -144,7 +144,7 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
   {
     static unsigned long long* buf = nullptr;
     static size_t cap = 0;
-    const size_t n = (size_t)grid * kWaves * 8;
+    const size_t n = (size_t)grid * (threads / 64) * 8;
     if (n > cap) {
       (void)hipMalloc(&buf, n * 8);
       cap = n;
@@ -152,23 +152,26 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
     (void)hipMemsetAsync(buf, 0, n * 8, stream);
     FwdParams prm2 = prm;
     prm2.stamps = buf;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, prm2);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, prm2);
     (void)hipStreamSynchronize(stream);
     std::vector<unsigned long long> h(n);
     (void)hipMemcpy(h.data(), buf, n * 8, hipMemcpyDeviceToHost);
-    double ph[4] = {0, 0, 0, 0};
+    double ph[4] = {0, 0, 0, 0}, cold = 0, items = 0;
     size_t cnt = 0;
     for (size_t i = 0; i < n; i += 8) {
       if (h[i + 4] == 0) continue;  // kernel without stamps
       for (int k = 0; k < 4; ++k) ph[k] += (double)(h[i + k + 1] - h[i + k]);
+      cold += (double)h[i + 5];   // persistent kernel only: cycles before the first item's S(0)
+      items += (double)h[i + 6];  // persistent kernel only: items the workgroup went through
       ++cnt;
     }
     if (cnt)
-      fprintf(stderr, "[stamps] cycles per wave: prologue %.0f  loop %.0f  tail+epilogue issue %.0f  store drain %.0f  (%zu waves)\n",
-              ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, cnt);
+      fprintf(stderr, "[stamps] s_memtime ticks per wave: prologue %.0f  loop %.0f  tail+epilogue issue %.0f  store drain %.0f  "
+                      "cold start %.0f  items %.2f  (%zu waves)\n",
+              ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, cold / cnt, items / cnt, cnt);
   }
 #else
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, stream, prm);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, prm);
 #endif
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "kernel launch failed: %s", hipGetErrorString(e));
@@ -216,12 +219,41 @@ static uint32_t persistent_grid(uint32_t items) {
   return items < g ? items : (g ? g : 8u);
 }
 
+// Sequences up to this length run the persistent d = 128 kernel in the eight-wave layout (two waves per
+// SIMD, 32 query rows each): the two waves of a SIMD fill each other's matrix-pipe gaps at the item
+// boundaries, which is what short items are made of.  Longer sequences measure the same in both
+// layouts and keep the four-wave one (half the LDS reads).  d = 64 gains nothing from it at any length.
+// FLASH_HIP_WIDE_MAX_N overrides the limit (A/B measurements; read on every call).
+static int64_t wide_max_n() {
+  const char* e = getenv("FLASH_HIP_WIDE_MAX_N");
+  return e ? atoll(e) : 2048;
+}
+static bool use_wide(int tile_d, int64_t N) { return tile_d == 128 && N <= wide_max_n(); }
+
+// the eight-wave layout's name for an output type (the bfloat16 tag is declared per layout)
+template <typename TO>
+struct WideOut {
+  using type = TO;
+};
+template <>
+struct WideOut<m16::bf16_out> {
+  using type = m16w::bf16_out;
+};
+
 // whole query tiles (N % 256 == 0): persistent workgroups with uninterrupted K/V staging
 template <int D, typename TO>
 int launch_m16p(const FwdParams& prm, hipStream_t stream) {
   static thread_local bool attr_done[16] = {};
   return launch_kernel(m16::attn_fwd_kernel_m16p<D, TO>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream, attr_done,
-                       persistent_grid(prm.total_wg));
+                       persistent_grid(prm.total_wg), (uint32_t)m16::kThreads);
+}
+template <typename TO>
+int launch_m16p_wide(const FwdParams& prm, hipStream_t stream) {
+  static thread_local bool attr_done[16] = {};
+  static_assert(m16w::CfgP<128>::kLdsBytes == m16::CfgP<128>::kLdsBytes, "both layouts use the same LDS rings");
+  return launch_kernel(m16w::attn_fwd_kernel_m16p<128, typename WideOut<TO>::type>, prm,
+                       (uint32_t)m16w::CfgP<128>::kLdsBytes, stream, attr_done, persistent_grid(prm.total_wg),
+                       (uint32_t)m16w::kThreads);
 }
 
 // fp16 Q, K, V with 16-byte row chunks, O as fp16 or fp32
@@ -231,8 +263,10 @@ int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t s
                 "both kernel families use the same LDS rings");
   // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
   // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
-  if (N % kBr == 0 && N <= persistent_max_n() && use_persistent())
+  if (N % kBr == 0 && N <= persistent_max_n() && use_persistent()) {
+    if (use_wide(plan.tile_d, N)) return launch_m16p_wide<TO>(prm, stream);
     return plan.tile_d == 64 ? launch_m16p<64, TO>(prm, stream) : launch_m16p<128, TO>(prm, stream);
+  }
   return plan.tile_d == 64 ? launch_m16<64, TO>(prm, plan.lds, stream) : launch_m16<128, TO>(prm, plan.lds, stream);
 }
 
@@ -412,7 +446,7 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->lds_bytes = !persistent ? plan.lds
                                : (uint32_t)(plan.tile_d == 64 ? m16::CfgP<64>::kLdsBytes : m16::CfgP<128>::kLdsBytes);
   out->block_x = 64;
-  out->block_y = kWaves;
+  out->block_y = persistent && use_wide(plan.tile_d, N) ? (uint32_t)m16w::kWaves : (uint32_t)kWaves;
   out->grid_x = (uint32_t)B;
   out->grid_y = (uint32_t)H;
   out->grid_z = plan.nqt;

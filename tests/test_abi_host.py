@@ -33,14 +33,19 @@ def test_kernel_type_names_match_reference_order(fa):
 
 
 def test_geometry_query(fa):
-    # GPT-3 head shape: 8 query tiles of 256 rows, 4 waves of 64 lanes (one per SIMD); whole tiles run on
+    # GPT-3 head shape: 16 query tiles of 256 rows, 4 waves of 64 lanes (one per SIMD); whole tiles run on
     # the persistent kernel: 4 K + 4 V tiles of 64 x 128 halves = 128 KiB of LDS
-    info = fa.launch_info(4, 96, 2048, 128, fa.KernelType.mma_qreg_async)
+    info = fa.launch_info(4, 96, 4096, 128, fa.KernelType.mma_qreg_async)
     assert info.tile_size == (64, 256, 128)
     assert info.block_dim == (64, 4)
-    assert info.grid_dim == (4, 96, 8)
+    assert info.grid_dim == (4, 96, 16)
     assert info.sram_size == 131072 and info.sram_size <= 160 * 1024
     assert info.staging == 2 and info.aligned_rows
+    # up to N = 2048 the same tile is worked by 8 waves of 32 query rows (two per SIMD)
+    info = fa.launch_info(4, 96, 2048, 128, fa.KernelType.mma_qreg_async)
+    assert info.tile_size == (64, 256, 128) and info.block_dim == (64, 8) and info.grid_dim == (4, 96, 8)
+    assert info.sram_size == 131072 and info.persistent
+    assert fa.launch_info(16, 32, 2048, 64).block_dim == (64, 4)      # small heads keep four waves
     # small heads use the 64-wide tile; ragged N rounds the grid up
     info = fa.launch_info(16, 32, 2049, 64)
     assert info.tile_size == (64, 256, 64) and info.grid_dim == (16, 32, 9) and info.sram_size == 49152

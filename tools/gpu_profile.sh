@@ -1,10 +1,22 @@
-mkdir -p gpurun_out/prof && cd /root/repo
+# rocprofv3 passes for one workload:  bash tools/gpu_profile.sh <workload> "<B H N d>" [outdir]
+#   kernel trace + stats of `bench.py --workload <workload>`, then one PMC pass per counter group over
+#   `tests/native/selftest bench <B H N d> 5 11` (the same kernel through the C ABI, no torch).
+# LIBDIR=<dir> profiles another build of libflash_hip.so (PMC passes only).
+set -o pipefail
+W=${1:-headline}; SHAPE=${2:-"8 96 4096 128"}; OUT=${3:-gpurun_out/prof/$W}
+mkdir -p $OUT && cd /root/repo
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/kt -o bench -- python3 bench.py --no-cpu-baseline > gpurun_out/prof/bench_prof.json 2> gpurun_out/prof/kt.err || { tail -30 gpurun_out/prof/kt.err; exit 1; }
-cat gpurun_out/prof/bench_prof.json
-find gpurun_out/prof/kt -type f | head
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/fetch -o p -- tests/native/selftest bench 8 96 4096 128 5 11 > gpurun_out/prof/fetch.log 2>&1 || { tail gpurun_out/prof/fetch.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof/write -o p -- tests/native/selftest bench 8 96 4096 128 5 11 > gpurun_out/prof/write.log 2>&1 || { tail gpurun_out/prof/write.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d gpurun_out/prof/sq -o p -- tests/native/selftest bench 8 96 4096 128 5 11 > gpurun_out/prof/sq.log 2>&1 || { tail gpurun_out/prof/sq.log; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_MFMA --output-format csv -d gpurun_out/prof/grbm -o p -- tests/native/selftest bench 8 96 4096 128 5 11 > gpurun_out/prof/grbm.log 2>&1 || { tail gpurun_out/prof/grbm.log; exit 1; }
-find gpurun_out/prof -type f | head -40
+[ -n "$LIBDIR" ] && export LD_LIBRARY_PATH=$LIBDIR
+if [ -z "$LIBDIR" ]; then
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py --workload $W --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/kt.err || { tail -30 $OUT/kt.err; exit 1; }
+cat $OUT/bench_prof.json
+fi
+pass() {  # name, counters...
+  local name=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- tests/native/selftest bench $SHAPE 5 11 > $OUT/$name.log 2>&1 || { tail $OUT/$name.log; exit 1; }
+}
+pass fetch FETCH_SIZE &&
+pass write WRITE_SIZE &&
+pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU &&
+pass grbm GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_MFMA &&
+find $OUT -name "*.csv" | head -20
