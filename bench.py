@@ -41,6 +41,11 @@ WORKLOADS = {
     "d64": (16, 32, 2048, 64),        # configs[3]
     "tiny": (2, 4, 256, 64),          # configs[0]
 }
+# Default (steps, warmup) per workload: a timed region of a few tenths of a second.  The chip takes
+# milliseconds to settle its clock under a new load, so 50 launches of a 0.2 ms kernel would time the
+# ramp and not the kernel (measured: 0.235 ms per launch in such a burst against 0.198 ms sustained).
+DEFAULT_STEPS = {"headline": (50, 5), "gpt3_4k_b4": (100, 10), "gpt3_2k": (400, 40), "gpt3_1k": (1500, 150),
+                 "d64": (600, 60), "tiny": (2000, 200)}
 PEAK_TFLOPS_FP16_DENSE = 2500.0       # MI355X dense fp16/bf16 MFMA peak (256 CU x 4096 flop/clk x 2.4 GHz)
 
 
@@ -123,8 +128,8 @@ def launch_ranks(n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: per workload, see DEFAULT_STEPS)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: per workload)")
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel-type", default="mma_qreg_async")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"],
@@ -141,6 +146,11 @@ def main():
                          "head chunks (reported beside the metric, never part of `value`)")
     ap.add_argument("--gather-exchange", default="p2p", choices=["p2p", "all_gather"])
     args = ap.parse_args()
+
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS[args.workload][0]
+    if args.warmup is None:
+        args.warmup = DEFAULT_STEPS[args.workload][1]
 
     # N > 1 without a launcher around us: become the launcher, before anything GPU-related is imported
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -37,6 +37,15 @@ constexpr int kThreads = kWaves * 64;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Timing-only diagnostic builds (-DFLASH_KNOCKOUT=<mask>, results are wrong): leave one kind of
+// per-step work out of the pipeline steps to see what it costs.  1 exponentials, 2 K/V staging,
+// 4 LDS fragment reads, 8 conversions of P to 16 bit, 16 row sums, 32 running maximum, 64 the score
+// multiply.  tools/ceiling.sh builds and times them.
+#ifndef FLASH_KNOCKOUT
+#define FLASH_KNOCKOUT 0
+#endif
+constexpr int kKnock = FLASH_KNOCKOUT;
+
 constexpr int kQ16 = kRowsPerWave / 16;  // 16-row query blocks per wave
 constexpr int kRing = 3;                 // tiles per LDS ring
 static_assert((kWaves == 4 && kQ16 == 4) || (kWaves == 8 && kQ16 == 2),
@@ -363,11 +372,13 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     x = __builtin_bit_cast(f16x2, w);
   };
   // row sum of query block q's fragment, whose last pair was packed two elements ago
-  auto group_add = [&](int q) __attribute__((always_inline)) { mfma_rowsum<D, EK>(lsum[q], q, ones_row, p_cur[q]); };
+  auto group_add = [&](int q) __attribute__((always_inline)) {
+    if constexpr (!(kKnock & 16)) mfma_rowsum<D, EK>(lsum[q], q, ones_row, p_cur[q]);
+  };
   auto finish = [&](int g) __attribute__((always_inline)) {
     const int q = g / 8, e = g % 8;
     if ((g & 7) == 1 && g >= 9) group_add(g / 8 - 1);
-    if ((g & 1) != 0) {
+    if ((g & 1) != 0 && !(kKnock & 8)) {
       f16x2 w = __builtin_bit_cast(f16x2, pack2<EK>(t_exp_prev, t_exp));
       pin(w);
       p_cur[q][e - 1] = w[0];
@@ -375,13 +386,14 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     }
     t_exp_prev = t_exp;
   };
-  // The residual scale factor is one v_mul_f32 per score (a packed v_pk_mul_f32 issues in twice the
-  // time of a plain multiply on this chip, so pairing gains nothing), issued one score ahead of the
+  // The scale factor is one v_mul_f32 per score (a packed v_pk_mul_f32 over register pairs issues in
+  // twice the time of a plain multiply on this chip and measured 1-2 % slower), issued one score ahead of the
   // exponential that consumes it so that the exponential never waits for its operand.
   float x_cur = 0.f, x_nxt = 0.f;
   auto scaled = [&](int g) __attribute__((always_inline)) {
     // (no register pin here: an asm statement that names the product makes the compiler pad the
     // exponential behind it with a wait state)
+    if constexpr (kKnock & 64) return s_cur[(g % 8) / 4][g / 8][g % 4];
     return s_cur[(g % 8) / 4][g / 8][g % 4] * sc.c;
   };
   auto exp_share = [&](int n) __attribute__((always_inline)) {
@@ -389,7 +401,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
     for (int g = n * ELEMS / SLOTS; g < (n + 1) * ELEMS / SLOTS; ++g) {
       if (g > 0) finish(g - 1);
       if (g == 0) x_cur = scaled(0);
-      t_exp = fast_exp2(x_cur);
+      t_exp = (kKnock & 1) ? x_cur : fast_exp2(x_cur);
       asm volatile("" : "+v"(t_exp));
       if (g + 1 < ELEMS) x_nxt = scaled(g + 1);
       x_cur = x_nxt;
@@ -401,6 +413,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
   // op u values 2u+1 and 2u+2, the last op value 31.
   auto score = [&](int v) __attribute__((always_inline)) { return s_nxt[(v % 8) / 4][v / 8][v % 4]; };
   auto max_op = [&](int u) __attribute__((always_inline)) {
+    if constexpr (kKnock & 32) return;
     if constexpr (MASKED) {
       // keys beyond N of a query block, right before the chain first touches the block
       const int q_new = u == 0 ? 0 : ((2 * u + 2) % 8 == 0 ? (2 * u + 2) / 8 : -1);
@@ -436,7 +449,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
           mfma_s<false, EK>(s_nxt[kb][q], ka[f % 4], qf[q][ks]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (q == kQ16 - 1) {
+        if (q == kQ16 - 1 && !(kKnock & 4)) {
           if (f + 4 < 2 * kKS) {
             ka[f % 4] = read_k<D>(kb_off, la, (f + 4) / kKS, (f + 4) % kKS);
           } else if constexpr (HAS_PRELOAD) {
@@ -446,12 +459,12 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
       }
       // the first four V^T fragments, shortly before the PV slots begin
       constexpr int V_FIRST = QK_SLOTS >= 10 ? QK_SLOTS - 10 : 0;
-      if (PV_MODE != kPvSkip && n >= V_FIRST && n < V_FIRST + 8 && ((n - V_FIRST) & 1) == 0) {
+      if (PV_MODE != kPvSkip && !(kKnock & 4) && n >= V_FIRST && n < V_FIRST + 8 && ((n - V_FIRST) & 1) == 0) {
         const int b = (n - V_FIRST) / 2;
         va[b] = read_v<D>(vb_off, la, b);
       }
       exp_share(n);
-      hook(n);
+      if constexpr (!(kKnock & 2)) hook(n);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -467,9 +480,9 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
         mfma_o<false, EK>(o[q][b], va[b % 4], p_prev[q]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (PV_MODE != kPvSkip && q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
+      if (PV_MODE != kPvSkip && !(kKnock & 4) && q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
       exp_share(QK_SLOTS + pslot);
-      hook(QK_SLOTS + pslot);
+      if constexpr (!(kKnock & 2)) hook(QK_SLOTS + pslot);
       if constexpr (HAS_QK) {
 #pragma unroll
         for (int u = 0; u < MAX_OPS; ++u) {
