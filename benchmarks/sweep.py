@@ -28,7 +28,7 @@ Every sequence length is also a parity check: the last head of the native output
 CPU oracle (fp32 softmax(QK^T/sqrt(d))V on the same fp16 inputs) and the script exits non-zero if
 max-abs exceeds 2e-3 or any element leaves 2e-3 + 1e-2*|ref|.
 
-  python benchmarks/sweep.py [--out profiles/sweep.json] [--max-n 16384] [--reps 10]
+  python benchmarks/sweep.py [--out profiles/sweep.json] [--max-n 16384] [--reps 10] [--min-seconds 0.25]
 """
 from __future__ import annotations
 
@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--max-n", type=int, default=16384)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--min-seconds", type=float, default=0.25, help="least length of a timed burst")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--heads", type=int, default=96)
     ap.add_argument("--head-dim", type=int, default=128)
@@ -80,19 +81,26 @@ def main():
     ]
 
     def time_ms(fn, q, k, v):
-        """Average over `reps` back-to-back calls (sustained clocks; single calls separated by host
-        synchronisation run at boost clocks and read up to 15 % faster at short sequences)."""
+        """Average over back-to-back calls that fill at least `--min-seconds` (and at least `--reps`
+        calls): the chip needs milliseconds to settle its clock under a new load, so a burst of ten short
+        calls times the ramp (N = 512: 0.09 ms per call in such a burst against 0.055 ms sustained), and
+        single calls separated by host synchronisation run at boost clocks."""
+        def burst(n):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn(q, k, v)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / n
+
         for _ in range(3):
             fn(q, k, v)
         torch.cuda.synchronize(dev)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            fn(q, k, v)
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / args.reps
+        est = burst(args.reps)
+        n = max(args.reps, min(5000, int(args.min_seconds * 1e3 / max(est, 1e-3)) + 1))
+        return burst(n) if n > args.reps else est
 
     def profiler_ms(fn, q, k, v):
         """The reference's profile_kernel (benchmarks/bench.py:58-66): sum of self device time of one call."""
