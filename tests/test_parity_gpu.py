@@ -196,6 +196,32 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
             f"d={d}: {(err_rows > ATOL).mean():.3f} of the rows off, max {err_rows.max():.3e}")
 
 
+def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monkeypatch):
+    """The persistent d = 128 kernel exists in two wave layouts (four waves x 64 query rows, eight waves
+    x 32) and the library picks by sequence length.  FLASH_HIP_WIDE_MAX_N (read on every call) forces
+    either one: both must meet the bar on the same inputs, for fp16 and for fp32 tensors through the
+    workspace (fp32 output), with several items per workgroup at the second shape."""
+    torch = torch_gpu
+    for shape in ((1, 5, 768, 128), (3, 200, 512, 128)):
+        rng = np.random.default_rng(shape[2])
+        q, k, v = (oracle.round_f16(rng.standard_normal(shape).astype(np.float32)) for _ in range(3))
+        heads = [(0, 0), (shape[0] - 1, shape[1] - 1), (shape[0] // 2, shape[1] // 3)]
+        ref = {bh: oracle.attn_naive(*(x[bh[0]:bh[0] + 1, bh[1]:bh[1] + 1] for x in (q, k, v)))[0, 0] for bh in heads}
+        outs = []
+        for limit, waves in (("0", 4), ("1000000", 8)):
+            monkeypatch.setenv("FLASH_HIP_WIDE_MAX_N", limit)
+            assert fa.launch_info(*shape).block_dim == (64, waves)
+            for dtype, ws in ((torch.float16, False), (torch.float32, True)):
+                o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
+                for bh in heads:
+                    assert_close(o[bh], ref[bh], f"{shape} head {bh} {waves} waves {dtype}")
+                outs.append(o)
+        monkeypatch.delenv("FLASH_HIP_WIDE_MAX_N")
+        # same arithmetic per query row in both layouts (only the wave-wide decision to move a reference
+        # can fall differently): the fp16 results agree far inside the bar
+        assert np.abs(outs[0] - outs[2]).max() <= 2e-4, f"{shape}: the two layouts differ"
+
+
 # ---- full-size configurations: size-independent properties + sampled heads vs the oracle ----------
 FULL = [(4, 96, 1024, 128), (16, 32, 2048, 64), (4, 96, 4096, 128)]
 
