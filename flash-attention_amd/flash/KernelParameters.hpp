@@ -27,9 +27,10 @@ class KernelParametersBase {
   virtual ~KernelParametersBase() = default;
 };
 
-// Geometry of the wave64 MFMA kernel: 4 waves (one per SIMD) x 64 query rows per workgroup
-// (Br = 256), 64-row K/V tiles (Bc), head dim padded to 64 or 128, rings of three K and three V
-// tiles in LDS.
+// Geometry of the wave64 MFMA kernel: 256 query rows per workgroup (Br), worked by 4 waves (one per
+// SIMD) x 64 rows or, for whole-tile d = 128 shapes up to N = 2048, by 8 waves x 32 rows; 64-row K/V
+// tiles (Bc), head dim padded to 64 or 128, rings of three (persistent kernel: four) K and as many V
+// tiles in LDS.  The numbers come from the library (flash_fwd_query), not from this header.
 // Replaces MMAQregParameters / MMAQregAsyncParameters (reference flash/KernelParameters.hpp:332-381).
 class MFMAQregParameters : public KernelParametersBase {
   flash_launch_info info_{};
