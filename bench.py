@@ -277,7 +277,7 @@ def main():
     if rank == 0:
         info = fa.launch_info(B, H, N, d, kt, fa.ENTRY_BF16 if args.dtype == "bf16" else fa.ENTRY_F16)
         pers = info.persistent    # what the library routes this shape to right now (environment included)
-        ns = "m16w" if info.block_dim[1] == 8 else "m16"
+        ns = "m16w" if info.block_dim[1] == 8 else ("m16x" if info.tile_size[1] == 512 else "m16")
         flops = attention_flops(*shape)
         value = world * flops * args.steps / elapsed / 1e12
         achieved = flops / (kernel_ms * 1e-3) / 1e12
@@ -310,7 +310,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
                 "traffic": measured_traffic(args.workload),
-                # ns: the wave layout the library picked (m16 = 4 waves x 64 query rows, m16w = 8 x 32)
+                # ns: the wave layout the library picked (m16 = 4 waves x 64 query rows, m16w = 8 x 32, m16x = 4 x 128)
                 "kernel": "flash_hip::{ns}::attn_fwd_kernel_m16{}<{}, {}>".format(
                     "p" if pers else "", 128 if d > 64 else 64,
                     "_Float16" if args.dtype == "fp16" else "flash_hip::{ns}::bf16_out", ns=ns).format(ns=ns),

@@ -1,5 +1,5 @@
 // FlashAttention-2 forward for gfx950 on v_mfma_f32_16x16x32_f16: the kernels of
-// attn_fwd_mfma16_body.hpp in two wave layouts of the same 256-row query tile.
+// attn_fwd_mfma16_body.hpp in three wave layouts.
 //   m16   four waves (one per SIMD), 64 query rows each: the least LDS traffic per FLOP.
 //   m16w  eight waves (two per SIMD), 32 query rows each: every K/V fragment is read from LDS by twice
 //         as many waves, but while one wave of a SIMD is in the vector-only stretch between two work
@@ -7,17 +7,34 @@
 //         the matrix pipe busy.  Same speed on long sequences (the chip is power-limited there: 10 %
 //         fewer cycles at a 10 % lower clock), faster where items are short: +10 % at N = 512, +3 % at
 //         N = 1024, +1 % at N = 2048 for (4, 96, N, 128).
+//   m16x  four waves, 128 query rows each, 512-row query tile: d = 64 only (O^T and Q then take the 192
+//         accumulation registers they take at d = 128 with 64 rows; the score and probability tiles fill
+//         all 256 vector registers).  Half the K/V staging traffic and half the LDS fragment reads per
+//         FLOP, which is where d = 64 spends twice the energy per FLOP of d = 128: +7.5 % at
+//         (16, 32, 2048, 64), +8 % at N = 8192.  Whole 512-row tiles only.
 #pragma once
 #include "attn_fwd_mfma.hpp"
 
 #define FLASH_M16_NS m16
 #define FLASH_M16_ROWS 64
+#define FLASH_M16_WAVES 4
 #include "attn_fwd_mfma16_body.hpp"
 #undef FLASH_M16_NS
 #undef FLASH_M16_ROWS
+#undef FLASH_M16_WAVES
 
 #define FLASH_M16_NS m16w
 #define FLASH_M16_ROWS 32
+#define FLASH_M16_WAVES 8
 #include "attn_fwd_mfma16_body.hpp"
 #undef FLASH_M16_NS
 #undef FLASH_M16_ROWS
+#undef FLASH_M16_WAVES
+
+#define FLASH_M16_NS m16x
+#define FLASH_M16_ROWS 128
+#define FLASH_M16_WAVES 4
+#include "attn_fwd_mfma16_body.hpp"
+#undef FLASH_M16_NS
+#undef FLASH_M16_ROWS
+#undef FLASH_M16_WAVES

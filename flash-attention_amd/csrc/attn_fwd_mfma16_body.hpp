@@ -24,15 +24,16 @@
 //     4g.. of rows 0..15 and of rows 16..31 of the block), B = P^T fragment, K = all 32 keys.
 //
 // This file is the body of both wave layouts and is included once per layout by attn_fwd_mfma16.hpp,
-// which sets FLASH_M16_NS (the namespace) and FLASH_M16_ROWS (query rows per wave: 64 = four waves, one
-// per SIMD; 32 = eight waves, two per SIMD).  Names of the wave geometry declared here shadow the ones
+// which sets FLASH_M16_NS (the namespace), FLASH_M16_ROWS (query rows per wave) and FLASH_M16_WAVES
+// (64 x 4: one wave per SIMD; 32 x 8: two per SIMD; 128 x 4: one per SIMD, d = 64 only).  Names of the wave geometry declared here shadow the ones
 // of attn_fwd_mfma.hpp inside the namespace.
 
 namespace flash_hip {
 namespace FLASH_M16_NS {
 
 constexpr int kRowsPerWave = FLASH_M16_ROWS;
-constexpr int kWaves = kBr / kRowsPerWave;
+constexpr int kWaves = FLASH_M16_WAVES;
+constexpr int kBr = kWaves * kRowsPerWave;  // query rows per workgroup: 256, or 512 in the 128-rows-per-wave layout
 constexpr int kThreads = kWaves * 64;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -48,8 +49,8 @@ constexpr int kKnock = FLASH_KNOCKOUT;
 
 constexpr int kQ16 = kRowsPerWave / 16;  // 16-row query blocks per wave
 constexpr int kRing = 3;                 // tiles per LDS ring
-static_assert((kWaves == 4 && kQ16 == 4) || (kWaves == 8 && kQ16 == 2),
-              "one wave per SIMD with 64 query rows, or two with 32 each");
+static_assert((kWaves == 4 && kQ16 == 4) || (kWaves == 8 && kQ16 == 2) || (kWaves == 4 && kQ16 == 8),
+              "one wave per SIMD with 64 query rows, two with 32 each, or one with 128 (d = 64 only)");
 
 template <int D>
 struct Cfg {
@@ -190,12 +191,25 @@ typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
     default:                                                              \
     FLASH_LSUM_CASE(3, "a[204:207]", "a[108:111]", TEXT, __VA_ARGS__)     \
   }
-#else  // two query blocks per wave: O^T and Q take half the registers
+#elif FLASH_M16_ROWS == 32  // two query blocks per wave: O^T and Q take half the registers
 #define FLASH_LSUM_SWITCH(q, TEXT, ...)                                   \
   switch (q) {                                                            \
     FLASH_LSUM_CASE(0, "a[96:99]", "a[48:51]", TEXT, __VA_ARGS__)         \
     default:                                                              \
     FLASH_LSUM_CASE(1, "a[100:103]", "a[52:55]", TEXT, __VA_ARGS__)       \
+  }
+#else  // eight query blocks per wave, d = 64 only: O^T 128 registers, Q 64
+#define FLASH_LSUM_SWITCH(q, TEXT, ...)                                   \
+  switch (q) {                                                            \
+    FLASH_LSUM_CASE(0, "a[192:195]", "a[192:195]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(1, "a[196:199]", "a[196:199]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(2, "a[200:203]", "a[200:203]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(3, "a[204:207]", "a[204:207]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(4, "a[208:211]", "a[208:211]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(5, "a[212:215]", "a[212:215]", TEXT, __VA_ARGS__)     \
+    FLASH_LSUM_CASE(6, "a[216:219]", "a[216:219]", TEXT, __VA_ARGS__)     \
+    default:                                                              \
+    FLASH_LSUM_CASE(7, "a[220:223]", "a[220:223]", TEXT, __VA_ARGS__)     \
   }
 #endif
 // `q` must be a compile-time constant at the call site after inlining (the other cases fold away).
@@ -248,8 +262,13 @@ __device__ __forceinline__ void drain_s(f32x4 (&s)[2][kQ16]) {
     asm volatile("s_nop 15\n\ts_nop 15"
                  : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]),
                    "+v"(s[1][2]), "+v"(s[1][3]));
-  } else {
+  } else if constexpr (kQ16 == 2) {
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));
+  } else {
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[0][4]), "+v"(s[0][5]),
+                   "+v"(s[0][6]), "+v"(s[0][7]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(s[1][2]), "+v"(s[1][3]),
+                   "+v"(s[1][4]), "+v"(s[1][5]), "+v"(s[1][6]), "+v"(s[1][7]));
   }
 }
 
@@ -523,8 +542,12 @@ __device__ __forceinline__ void drain_lsum(f32x4 (&lsum)[kQ16]) {
 __device__ __forceinline__ void bias_ready(f32x4 (&bias)[kQ16]) {
   if constexpr (kQ16 == 4) {
     asm volatile("s_nop 4" : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]));
-  } else {
+  } else if constexpr (kQ16 == 2) {
     asm volatile("s_nop 4" : "+v"(bias[0]), "+v"(bias[1]));
+  } else {
+    asm volatile("s_nop 4"
+                 : "+v"(bias[0]), "+v"(bias[1]), "+v"(bias[2]), "+v"(bias[3]), "+v"(bias[4]), "+v"(bias[5]),
+                   "+v"(bias[6]), "+v"(bias[7]));
   }
 }
 

@@ -240,6 +240,23 @@ struct WideOut<m16::bf16_out> {
   using type = m16w::bf16_out;
 };
 
+// d = 64 leaves room for 128 query rows per wave (O^T and Q take the registers they take at d = 128 with
+// 64 rows): a 512-row query tile per workgroup, i.e. half the K/V staging traffic and half the LDS
+// fragment reads per FLOP.  Whole 512-row tiles only.  FLASH_HIP_TALL=0 turns it off (A/B measurements).
+static bool use_tall(int tile_d, int64_t N) {
+  if (tile_d != 64 || N % m16x::kBr != 0) return false;
+  const char* e = getenv("FLASH_HIP_TALL");
+  return !(e && e[0] == '0');
+}
+template <typename TO>
+struct TallOut {
+  using type = TO;
+};
+template <>
+struct TallOut<m16::bf16_out> {
+  using type = m16x::bf16_out;
+};
+
 // whole query tiles (N % 256 == 0): persistent workgroups with uninterrupted K/V staging
 template <int D, typename TO>
 int launch_m16p(const FwdParams& prm, hipStream_t stream) {
@@ -265,6 +282,15 @@ int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t s
   // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
   if (N % kBr == 0 && N <= persistent_max_n() && use_persistent()) {
     if (use_wide(plan.tile_d, N)) return launch_m16p_wide<TO>(prm, stream);
+    if (use_tall(plan.tile_d, N)) {
+      FwdParams tall = prm;  // the same heads cut into 512-row query tiles
+      tall.nqt = (int)(N / m16x::kBr);
+      tall.total_wg = prm.total_wg / (uint32_t)prm.nqt * (uint32_t)tall.nqt;
+      static thread_local bool attr_done[16] = {};
+      return launch_kernel(m16x::attn_fwd_kernel_m16p<64, typename TallOut<TO>::type>, tall,
+                           (uint32_t)m16x::CfgP<64>::kLdsBytes, stream, attr_done, persistent_grid(tall.total_wg),
+                           (uint32_t)m16x::kThreads);
+    }
     return plan.tile_d == 64 ? launch_m16p<64, TO>(prm, stream) : launch_m16p<128, TO>(prm, stream);
   }
   return plan.tile_d == 64 ? launch_m16<64, TO>(prm, plan.lds, stream) : launch_m16<128, TO>(prm, plan.lds, stream);
@@ -439,7 +465,7 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
     return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
                 (long long)d);
   out->tile_kv = kBc;
-  out->tile_q = kBr;
+  out->tile_q = kBr;  // 512 for the 128-rows-per-wave layout, set below
   out->tile_d = (uint32_t)plan.tile_d;
   // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
   const bool persistent = plan.fast && N % kBr == 0 && N <= persistent_max_n() && use_persistent();
@@ -453,6 +479,10 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->staging = (uint32_t)plan.staging;
   out->aligned_rows = (d % 8 == 0) ? 1u : 0u;
   out->persistent = persistent ? 1u : 0u;
+  if (persistent && !use_wide(plan.tile_d, N) && use_tall(plan.tile_d, N)) {
+    out->tile_q = (uint32_t)m16x::kBr;
+    out->grid_z = (uint32_t)(N / m16x::kBr);
+  }
   return FLASH_HIP_OK;
 }
 

@@ -61,7 +61,7 @@ typedef enum flash_hip_kernel_type {
  */
 typedef struct flash_launch_info {
   uint32_t tile_kv;      /* Bc: K/V rows per LDS tile                (tileSize().x) */
-  uint32_t tile_q;       /* Br: Q rows per workgroup                 (tileSize().y) */
+  uint32_t tile_q;       /* Br: Q rows per workgroup: 256, or 512 for head dims <= 64 with N % 512 == 0 (tileSize().y) */
   uint32_t tile_d;       /* head dim padded to the compiled tile     (tileSize().z) */
   uint32_t lds_bytes;    /* dynamic LDS per workgroup                (sramSize())   */
   uint32_t block_x;      /* lanes per wave = 64                      (blockDim().x) */

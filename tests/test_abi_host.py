@@ -45,7 +45,11 @@ def test_geometry_query(fa):
     info = fa.launch_info(4, 96, 2048, 128, fa.KernelType.mma_qreg_async)
     assert info.tile_size == (64, 256, 128) and info.block_dim == (64, 8) and info.grid_dim == (4, 96, 8)
     assert info.sram_size == 131072 and info.persistent
-    assert fa.launch_info(16, 32, 2048, 64).block_dim == (64, 4)      # small heads keep four waves
+    # small heads keep four waves; whole 512-row tiles give every wave 128 query rows (tile_q 512)
+    info = fa.launch_info(16, 32, 2048, 64)
+    assert info.block_dim == (64, 4) and info.tile_size == (64, 512, 64) and info.grid_dim == (16, 32, 4)
+    assert info.sram_size == 2 * 4 * 64 * 128 and info.persistent
+    assert fa.launch_info(16, 32, 768, 64).tile_size == (64, 256, 64)    # 256-row tiles only
     # small heads use the 64-wide tile; ragged N rounds the grid up
     info = fa.launch_info(16, 32, 2049, 64)
     assert info.tile_size == (64, 256, 64) and info.grid_dim == (16, 32, 9) and info.sram_size == 49152

@@ -71,7 +71,7 @@ def hot_path(loop):
 
 def test_no_kernel_spills(asm_text):
     names = re.findall(r"\.name:\s+(_ZN9flash_hip\S*attn_fwd_kernel\S*)", asm_text)
-    assert len(names) >= 17, names
+    assert len(names) >= 20, names
     vals = re.findall(r"\.vgpr_spill_count:\s+(\d+)", asm_text)
     assert vals and all(v == "0" for v in vals), vals
     # scalar registers may overflow into lanes of a vector register (the persistent d=128 kernel keeps
@@ -90,6 +90,8 @@ TUNED = {
     "3m1620attn_fwd_kernel_m16pILi64E": (8 * 36, 4, 4),    # may rotate one step of them out of the loop)
     # eight-wave layout, two query blocks per wave: 16 QK + 16 PV + 2 row sums per step
     "4m16w20attn_fwd_kernel_m16pILi128E": (8 * 34, 4, 2),
+    # 128 query rows per wave (d = 64 only), eight query blocks: 32 QK + 32 PV + 8 row sums per step
+    "4m16x20attn_fwd_kernel_m16pILi64E": (8 * 72, 4, 8),
 }
 
 

@@ -222,6 +222,30 @@ def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monke
         assert np.abs(outs[0] - outs[2]).max() <= 2e-4, f"{shape}: the two layouts differ"
 
 
+def test_tall_layout_of_the_persistent_d64_kernel(fa, oracle, torch_gpu, monkeypatch):
+    """Head dims up to 64 with whole 512-row query tiles run with 128 query rows per wave (tile_q 512);
+    FLASH_HIP_TALL=0 (read on every call) keeps them on the 64-rows-per-wave layout.  Both must meet the
+    bar on the same inputs: fp16, fp32 through the workspace, a head dim below the tile width, and a
+    shape with several items per workgroup."""
+    torch = torch_gpu
+    for shape in ((2, 3, 1024, 64), (1, 2, 512, 40), (4, 300, 512, 64)):
+        rng = np.random.default_rng(shape[1])
+        q, k, v = (oracle.round_f16(rng.standard_normal(shape).astype(np.float32)) for _ in range(3))
+        heads = [(0, 0), (shape[0] - 1, shape[1] - 1), (shape[0] // 2, shape[1] // 3)]
+        ref = {bh: oracle.attn_naive(*(x[bh[0]:bh[0] + 1, bh[1]:bh[1] + 1] for x in (q, k, v)))[0, 0] for bh in heads}
+        outs = []
+        for flag, tile_q in (("0", 256), ("1", 512)):
+            monkeypatch.setenv("FLASH_HIP_TALL", flag)
+            assert fa.launch_info(*shape).tile_size[1] == tile_q
+            for dtype, ws in ((torch.float16, False), (torch.float32, True)):
+                o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
+                for bh in heads:
+                    assert_close(o[bh], ref[bh], f"{shape} head {bh} tile_q {tile_q} {dtype}")
+                outs.append(o)
+        monkeypatch.delenv("FLASH_HIP_TALL")
+        assert np.abs(outs[0] - outs[2]).max() <= 2e-4, f"{shape}: the two layouts differ"
+
+
 # ---- full-size configurations: size-independent properties + sampled heads vs the oracle ----------
 FULL = [(4, 96, 1024, 128), (16, 32, 2048, 64), (4, 96, 4096, 128)]
 
