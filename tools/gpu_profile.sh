@@ -8,7 +8,7 @@ mkdir -p $OUT && cd /root/repo
 export TMPDIR=/tmp
 [ -n "$LIBDIR" ] && export LD_LIBRARY_PATH=$LIBDIR
 if [ -z "$LIBDIR" ]; then
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py --workload $W --no-cpu-baseline > $OUT/bench_prof.json 2> $OUT/kt.err || { tail -30 $OUT/kt.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o bench -- python3 bench.py --workload $W --no-cpu-baseline --no-secondary > $OUT/bench_prof.json 2> $OUT/kt.err || { tail -30 $OUT/kt.err; exit 1; }
 cat $OUT/bench_prof.json
 fi
 pass() {  # name, counters...
