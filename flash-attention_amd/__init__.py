@@ -130,7 +130,7 @@ def to_string(kernel_type) -> str:
     return name.decode()
 
 
-ENTRY_F16, ENTRY_BF16, ENTRY_F32 = 0, 1, 2  # flash_hip_entry (include/flash_hip.h)
+ENTRY_F16, ENTRY_BF16, ENTRY_F32, ENTRY_F32_WS = 0, 1, 2, 3  # flash_hip_entry (include/flash_hip.h)
 
 
 def launch_info(B: int, H: int, N: int, d: int, kernel_type=KernelType.mma_qreg_async, entry: int = ENTRY_F16) -> LaunchInfo:
@@ -339,7 +339,7 @@ def forward_shard_gather(Qs, Ks, Vs, total_heads: int, kernel_type=KernelType.mm
 
 
 __all__ = [
-    "KernelType", "LaunchInfo", "ABI_SYMBOLS", "ENTRY_F16", "ENTRY_BF16", "ENTRY_F32", "lib", "to_string", "launch_info", "forward",
+    "KernelType", "LaunchInfo", "ABI_SYMBOLS", "ENTRY_F16", "ENTRY_BF16", "ENTRY_F32", "ENTRY_F32_WS", "lib", "to_string", "launch_info", "forward",
     "load_pyflash", "shard_heads", "forward_shard", "gather_output", "head_chunks",
     "forward_shard_gather",
     "LIB_PATH", "PYFLASH_PATH", "RUNNER_PATH", "REPO_ROOT",

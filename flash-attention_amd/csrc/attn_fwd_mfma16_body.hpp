@@ -665,6 +665,26 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
   }
 }
 
+// fp32 callers (TO = float): K and V come as fp16 copies out of the conversion pass (every K/V row is
+// read by N / Br workgroups), Q is read by exactly one workgroup and is taken from the caller's fp32
+// tensor directly, rounded to fp16 (nearest even, as the conversion pass rounds) on its way into the
+// registers: the pass moves a third fewer bytes.
+// (In the four-wave, 64-rows-per-wave layout only.  The 128-rows-per-wave layout has no vector registers
+// left to land fp32 Q in and neither has the eight-wave layout, which fp32 callers only get at N <= 512:
+// there the pass converts Q as well.)
+template <typename TO>
+constexpr bool kQFromF32 = std::is_same<TO, float>::value && kQ16 == 4;
+
+// Q fragment (8 consecutive head-dim elements of one query row) from its two 16-byte fp32 halves
+__device__ __forceinline__ f16x8 q_frag_from_f32(const u32x4& lo, const u32x4& hi) {
+  u32x4 w;
+  w[0] = pack2<kF16>(__uint_as_float(lo[0]), __uint_as_float(lo[1]));
+  w[1] = pack2<kF16>(__uint_as_float(lo[2]), __uint_as_float(lo[3]));
+  w[2] = pack2<kF16>(__uint_as_float(hi[0]), __uint_as_float(hi[1]));
+  w[3] = pack2<kF16>(__uint_as_float(hi[2]), __uint_as_float(hi[3]));
+  return __builtin_bit_cast(f16x8, w);
+}
+
 template <int D, typename TO = f16>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -693,11 +713,14 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
 
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
-  const f16* qh = (const f16*)p.q + (size_t)head * head_elems;
+  constexpr bool QF32 = kQFromF32<TO>;
+  constexpr uint32_t kQElem = QF32 ? 4u : 2u;
+  const char* qh = (const char*)p.q + (size_t)head * head_elems * kQElem;
   const f16* kh = (const f16*)p.k + (size_t)head * head_elems;
   const f16* vh = (const f16*)p.v + (size_t)head * head_elems;
   TO* oh = (TO*)p.o + (size_t)head * head_elems;
-  const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc((void*)qh, 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t q_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)qh, 0, (uint32_t)(head_elems * kQElem), 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs =
       __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, (uint32_t)(head_elems * sizeof(TO)), 0x00020000);
   const srd_t k_srd = make_srd(kh, head_bytes);
@@ -745,9 +768,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) {
       const int col = 8 * (ks + kKS * g);
-      const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * 2u : kOob;
+      const uint32_t off = (col < d) ? ((uint32_t)qrow[q] * (uint32_t)d + (uint32_t)col) * kQElem : kOob;
       const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
-      qf[q][ks] = __builtin_bit_cast(f16x8, raw);
+      if constexpr (QF32) {
+        qf[q][ks] = q_frag_from_f32(raw, __builtin_amdgcn_raw_buffer_load_b128(q_rs, off + 16u, 0, 0));
+      } else {
+        qf[q][ks] = __builtin_bit_cast(f16x8, raw);
+      }
     }
   }
   stage(k_srd, k_ring, 0, 0);
@@ -1002,6 +1029,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     __syncthreads();
   };
   auto head_of = [&](uint32_t it) __attribute__((always_inline)) { return it / (uint32_t)p.nqt; };
+  constexpr bool QF32 = kQFromF32<TO>;
+  constexpr uint32_t kQElem = QF32 ? 4u : 2u;
 
   // per-lane byte offsets of the Q chunks inside a head, for query tile 0 (a tile adds kBr rows)
   uint32_t q_off[kQ16][kKS];
@@ -1011,10 +1040,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     for (int ks = 0; ks < kKS; ++ks) {
       const int col = 8 * (ks + kKS * g);
       const uint32_t row = (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
-      q_off[q][ks] = (col < d) ? (row * (uint32_t)d + (uint32_t)col) * 2u : kOob;
+      q_off[q][ks] = (col < d) ? (row * (uint32_t)d + (uint32_t)col) * kQElem : kOob;
     }
   }
-  const uint32_t q_tile_bytes = (uint32_t)kBr * row_bytes;
+  const uint32_t q_tile_bytes = (uint32_t)kBr * (uint32_t)d * kQElem;
 
   f16x8 qf[kQ16][kKS];
   auto fetch_q = [&](uint32_t it) __attribute__((always_inline)) {
@@ -1030,10 +1059,52 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
   };
 
+  // fp32 Q: ordinary loads into vector registers (the compiler tracks them), converted later.  They are
+  // issued when the score and probability registers of the finished item are free, during its epilogue,
+  // in phases of at most 64 landing registers (the epilogue needs room of its own): phase ph covers
+  // query blocks [ph * kQPerPhase, (ph + 1) * kQPerPhase) and is converted behind the output stores of
+  // the same query blocks.
+  constexpr int kQPhases = (QF32 && kQ16 * kKS > 8) ? 2 : 1;
+  constexpr int kQPerPhase = kQ16 / kQPhases;
+  u32x4 q_land[QF32 ? kQPerPhase : 1][QF32 ? kKS : 1][2];
+  auto fetch_q32 = [&](uint32_t it, int ph) __attribute__((always_inline)) {
+    if constexpr (QF32) {
+      const uint32_t hd = head_of(it), qt = it - hd * (uint32_t)p.nqt;
+      const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)((const char*)p.q + (size_t)hd * head_elems * 4u), 0, (uint32_t)(head_elems * 4u), 0x00020000);
+#pragma unroll
+      for (int q = 0; q < kQPerPhase; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+          const uint32_t off = q_off[ph * kQPerPhase + q][ks] + qt * q_tile_bytes;
+          q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
+          q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off + 16u, 0, 0);
+        }
+      }
+    }
+  };
+  auto convert_q32 = [&](int ph) __attribute__((always_inline)) {
+    if constexpr (QF32) {
+#pragma unroll
+      for (int q = 0; q < kQPerPhase; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+          f16x8& dst = qf[ph * kQPerPhase + q][ks];
+          dst = q_frag_from_f32(q_land[q][ks][0], q_land[q][ks][1]);
+          asm volatile("" : "+a"(dst));
+        }
+      }
+    }
+  };
+
   // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
   srd_t k_srd = make_srd((const f16*)p.k + (size_t)head_of(item) * head_elems, head_bytes);
   srd_t v_srd = make_srd((const f16*)p.v + (size_t)head_of(item) * head_elems, head_bytes);
-  fetch_q(item);
+  if constexpr (QF32) {
+    fetch_q32(item, 0);
+  } else {
+    fetch_q(item);
+  }
 #pragma unroll
   for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 0, 0, i);
 #pragma unroll
@@ -1041,7 +1112,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 #pragma unroll
   for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 1, 1, i);
   const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
-  wait_q<0>(qf);
+  if constexpr (QF32) {
+    convert_q32(0);
+    if constexpr (kQPhases > 1) {
+      fetch_q32(item, 1);
+      convert_q32(1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staging pieces
+  } else {
+    wait_q<0>(qf);
+  }
   __syncthreads();
 
   f32x4 o[kQ16][kDv16];
@@ -1154,14 +1234,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       if constexpr (LAST) {
         // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
         // loads have the last step, the last P V product and the output stores to land.
-        if (has_next) fetch_q(next_item);
+        if constexpr (!QF32) {
+          if (has_next) fetch_q(next_item);
+        }
       }
       pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate, EK>(
           no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all, lsum, sc, pending, vote, 0, N, lane);
       step_end<kDv16, !LAST>(o, st, mx_all, lsum, bias, sA, pending, vote, sc, lane);
       if constexpr (LAST) {
         // wait for this wave's staging pieces, which are older than the Q loads, but not for those
-        if (has_next) {
+        if (has_next && !QF32) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQ16 * kKS) : "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1206,6 +1288,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
+      if constexpr (QF32) {
+        if (q % kQPerPhase == 0) {
+          // (the Q registers have been free since the item's last Q K^T product)
+          if (q > 0 && has_next) convert_q32(q / kQPerPhase - 1);
+          if (has_next) fetch_q32(next_item, q / kQPerPhase);
+        }
+      }
       const float inv = __builtin_amdgcn_rcpf(quad_lane_sum(lsum[q][0], lane));  // v_rcp_f32, 1 ulp
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
       store_o_block<kDv16, TO>(o[q], inv, qrow, d, g, o_rs);
@@ -1225,7 +1314,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 #endif
     if (!has_next) break;
     // the Q loads are older than this item's output stores: wait for everything but those stores
-    wait_q<kQ16 * OutStores<TO>::per_block(kDv16)>(qf);
+    if constexpr (QF32) {
+      convert_q32(kQPhases - 1);
+    } else {
+      wait_q<kQ16 * OutStores<TO>::per_block(kDv16)>(qf);
+    }
   #if defined(FLASH_PHASE_STAMPS)
     acc_pro += stamp_loop - stamp_item;
     acc_loop += stamp_tail - stamp_loop;

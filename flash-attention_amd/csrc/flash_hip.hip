@@ -273,6 +273,18 @@ int launch_m16p_wide(const FwdParams& prm, hipStream_t stream) {
                        (uint32_t)m16w::kThreads);
 }
 
+// which of the 16x16x32 kernels a whole-row-chunk shape goes to
+static bool routes_persistent(int64_t N) { return N % kBr == 0 && N <= persistent_max_n() && use_persistent(); }
+// fp32 callers (the fp16 kernels with fp32 output): beyond N = 512 they stay on the four-wave layout, whose
+// kernels read Q as fp32 themselves, which is worth more than the eight-wave layout (measured at
+// (4,96,N,128): N = 1024 +5..12 %, N = 512 -1 %)
+static bool routes_wide(const Plan& plan, int64_t N, bool fp32_out) {
+  return routes_persistent(N) && use_wide(plan.tile_d, N) && !(fp32_out && N > 512);
+}
+static bool routes_tall(const Plan& plan, int64_t N) {
+  return routes_persistent(N) && !use_wide(plan.tile_d, N) && use_tall(plan.tile_d, N);
+}
+
 // fp16 Q, K, V with 16-byte row chunks, O as fp16 or fp32
 template <typename TO>
 int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t stream) {
@@ -280,9 +292,9 @@ int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t s
                 "both kernel families use the same LDS rings");
   // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
   // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
-  if (N % kBr == 0 && N <= persistent_max_n() && use_persistent()) {
-    if (use_wide(plan.tile_d, N)) return launch_m16p_wide<TO>(prm, stream);
-    if (use_tall(plan.tile_d, N)) {
+  if (routes_persistent(N)) {
+    if (routes_wide(plan, N, std::is_same<TO, float>::value)) return launch_m16p_wide<TO>(prm, stream);
+    if (routes_tall(plan, N)) {
       FwdParams tall = prm;  // the same heads cut into 512-row query tiles
       tall.nqt = (int)(N / m16x::kBr);
       tall.total_wg = prm.total_wg / (uint32_t)prm.nqt * (uint32_t)tall.nqt;
@@ -348,9 +360,14 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
                 (long long)workspace_bytes, (long long)(kCastTensors * each));
   if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)hip_stream;
-  CastParams cp;
-  const void* src[kCastTensors] = {q, k, v};
-  for (int i = 0; i < kCastTensors; ++i) {
+  // K and V, which every query tile of a head re-reads; Q is read by one workgroup per row and the
+  // attention kernels take it from the caller's fp32 tensor (m16::kQFromF32), except in the
+  // 128-rows-per-wave and eight-wave layouts.  The workspace keeps its three-slot layout (K, V, then Q if converted).
+  const bool cast_q = routes_tall(plan, N) || routes_wide(plan, N, true);
+  const int n_cast = cast_q ? 3 : 2;
+  CastParams cp{};
+  const void* src[kCastTensors] = {k, v, q};
+  for (int i = 0; i < n_cast; ++i) {
     cp.src[i] = (const float*)src[i];
     cp.dst[i] = (f16*)((char*)workspace + (int64_t)i * each);
   }
@@ -358,10 +375,11 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   // enough workgroups to keep every CU's memory pipeline full, a few trips each at large sizes
   const uint64_t trips = (cp.n4 + kCastThreads * 4 - 1) / (kCastThreads * 4);
   const uint32_t gx = (uint32_t)(trips < 8192 ? (trips ? trips : 1) : 8192);
-  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, cp);
+  hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(gx, n_cast), dim3(kCastThreads), 0, stream, cp);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
-  const FwdParams prm = make_params(cp.dst[0], cp.dst[1], cp.dst[2], o, B, H, N, d, softmax_scale, plan, false);
+  const FwdParams prm =
+      make_params(cast_q ? (const void*)cp.dst[2] : q, cp.dst[0], cp.dst[1], o, B, H, N, d, softmax_scale, plan, false);
   return launch_fast<float>(prm, plan, N, stream);
 }
 
@@ -455,7 +473,7 @@ int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type,
 int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, int entry,
                           flash_launch_info* out) {
   if (!out) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null flash_launch_info");
-  if (entry < FLASH_ENTRY_F16 || entry > FLASH_ENTRY_F32)
+  if (entry < FLASH_ENTRY_F16 || entry > FLASH_ENTRY_F32_WS)
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "unknown entry point selector %d", entry);
   Plan plan;
   // flash_fwd_f32 (no workspace) stages fp32 elements through registers whatever the head dim
@@ -468,18 +486,18 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->tile_q = kBr;  // 512 for the 128-rows-per-wave layout, set below
   out->tile_d = (uint32_t)plan.tile_d;
   // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
-  const bool persistent = plan.fast && N % kBr == 0 && N <= persistent_max_n() && use_persistent();
+  const bool persistent = plan.fast && routes_persistent(N);
   out->lds_bytes = !persistent ? plan.lds
                                : (uint32_t)(plan.tile_d == 64 ? m16::CfgP<64>::kLdsBytes : m16::CfgP<128>::kLdsBytes);
   out->block_x = 64;
-  out->block_y = persistent && use_wide(plan.tile_d, N) ? (uint32_t)m16w::kWaves : (uint32_t)kWaves;
+  out->block_y = plan.fast && routes_wide(plan, N, entry == FLASH_ENTRY_F32_WS) ? (uint32_t)m16w::kWaves : (uint32_t)kWaves;
   out->grid_x = (uint32_t)B;
   out->grid_y = (uint32_t)H;
   out->grid_z = plan.nqt;
   out->staging = (uint32_t)plan.staging;
   out->aligned_rows = (d % 8 == 0) ? 1u : 0u;
   out->persistent = persistent ? 1u : 0u;
-  if (persistent && !use_wide(plan.tile_d, N) && use_tall(plan.tile_d, N)) {
+  if (plan.fast && routes_tall(plan, N)) {
     out->tile_q = (uint32_t)m16x::kBr;
     out->grid_z = (uint32_t)(N / m16x::kBr);
   }

@@ -80,9 +80,11 @@ typedef struct flash_launch_info {
 
 /* Which entry point a geometry query describes. */
 typedef enum flash_hip_entry {
-  FLASH_ENTRY_F16 = 0,  /* flash_fwd_f16, and flash_fwd_f32_ws with a workspace (same kernels) */
-  FLASH_ENTRY_BF16 = 1, /* flash_fwd_bf16 */
-  FLASH_ENTRY_F32 = 2   /* flash_fwd_f32, and flash_fwd_f32_ws without a usable workspace */
+  FLASH_ENTRY_F16 = 0,    /* flash_fwd_f16 */
+  FLASH_ENTRY_BF16 = 1,   /* flash_fwd_bf16 */
+  FLASH_ENTRY_F32 = 2,    /* flash_fwd_f32, and flash_fwd_f32_ws without a usable workspace */
+  FLASH_ENTRY_F32_WS = 3  /* flash_fwd_f32_ws with a workspace, flash_fwd_f32_static: the fp16 kernels with fp32
+                             output; the eight-wave layout only up to N = 512 */
 } flash_hip_entry;
 
 /*

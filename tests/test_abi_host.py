@@ -71,6 +71,11 @@ def test_geometry_query_per_entry_point(fa):
     f32 = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_F32)
     assert not f32.persistent and f32.staging == 0 and f32.sram_size == 2 * 3 * 64 * 256
     assert f32.grid_dim == f16.grid_dim and f32.block_dim == (64, 4)
+    # fp32 tensors through a workspace: the fp16 kernels with fp32 output, four waves beyond N = 512
+    ws = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_F32_WS)
+    assert ws.persistent and ws.staging == 2 and ws.block_dim == (64, 4) and f16.block_dim == (64, 8)
+    assert fa.launch_info(4, 96, 512, 128, entry=fa.ENTRY_F32_WS).block_dim == (64, 8)
+    assert fa.launch_info(16, 32, 2048, 64, entry=fa.ENTRY_F32_WS).tile_size == (64, 512, 64)
     with pytest.raises(ValueError, match="multiple of 8"):
         fa.launch_info(1, 1, 64, 50, fa.KernelType.mma_qreg, entry=fa.ENTRY_BF16)
     with pytest.raises(ValueError, match="entry point"):
