@@ -63,6 +63,15 @@ struct Plan {
 // the reference's: head dim above the largest compiled tile (launch.cu:270-280), odd head dim for
 // mma_qreg (:267-269), head dim not a multiple of 4 for the vector-load and async kernels
 // (:284-286, :301-303), unknown kernel type (:317).
+// The kernels take the running maximum over the unscaled scores, which orders them like the scaled ones
+// only for a positive scale (the reference has no such argument: it always uses 1 / sqrt(d),
+// launch.cu:192).
+int check_scale(float softmax_scale) {
+  if (!(softmax_scale > 0.f) || !std::isfinite(softmax_scale))
+    return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "softmax_scale must be positive and finite (got %g)", (double)softmax_scale);
+  return FLASH_HIP_OK;
+}
+
 int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool fp16_io, Plan* plan) {
   if (kernel_type < 0 || kernel_type >= FLASH_KT_COUNT)
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "Unsupported kernel type %d", kernel_type);
@@ -324,6 +333,7 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   Plan plan;
   int rc = make_plan(B, H, N, d, kernel_type, sizeof(T) == 2, &plan);
   if (rc != FLASH_HIP_OK) return rc;
+  if ((rc = check_scale(softmax_scale)) != FLASH_HIP_OK) return rc;
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
   hipStream_t stream = (hipStream_t)hip_stream;
   if constexpr (sizeof(T) == 2) {
@@ -353,6 +363,7 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   // convert while staging
   if (!plan.fast || !workspace || !aligned16(q, k, v, o))
     return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
+  if ((rc = check_scale(softmax_scale)) != FLASH_HIP_OK) return rc;
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
   const int64_t each = ws_tensor_bytes(B, H, N, d);
   if (workspace_bytes < kCastTensors * each)
@@ -429,6 +440,7 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
   if (!plan.fast)
     return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
                 (long long)d);
+  if ((rc = check_scale(softmax_scale)) != FLASH_HIP_OK) return rc;
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
   if (!aligned16(q, k, v, o))
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "bfloat16 tensors must be 16-byte aligned");

@@ -93,6 +93,8 @@ typedef enum flash_hip_entry {
  * (flash/launch.cu:197-204 KernelArgs, :216-318 dispatch, :130-183 launchKernel) and the kernels
  * kernel_mma_qreg / _f32x4load / _async (flash/kernel_mma_qreg*.cuh).
  * q, k, v, o: device pointers to IEEE binary16 data.  fp16 operands, fp32 accumulation.
+ * softmax_scale must be positive and finite (-> INVALID_ARGUMENT otherwise; the reference always uses
+ * 1 / sqrt(d), flash/launch.cu:192).
  * Errors mirror the reference: d > 128 -> UNSUPPORTED_DIM; kernel_type 9 needs d % 2 == 0, 10 and
  * 11 need d % 4 == 0 -> INVALID_ARGUMENT; unknown kernel_type -> INVALID_ARGUMENT.
  */
@@ -105,7 +107,7 @@ int flash_fwd_f16(const void* q, const void* k, const void* v, void* o,
  * cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation, bfloat16 output.  No counterpart in the
  * reference (its tensors are fp32, flash/launch.cu:165-176); offered because bfloat16 is the usual
  * storage type of the models this shape comes from.  d must be a multiple of 8 (-> UNSUPPORTED_DIM
- * otherwise); other errors as flash_fwd_f16.  P and Q * softmax_scale are rounded to 8 mantissa bits,
+ * otherwise); other errors as flash_fwd_f16.  P is rounded to 8 mantissa bits before the P V product,
  * so the error against an fp32 evaluation on the same inputs is several times that of fp16
  * (measured max-abs 1e-3 ... 7.4e-3 on standard-normal data; tested against 1.6e-2).
  */

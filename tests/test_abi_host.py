@@ -132,6 +132,11 @@ def test_null_pointer_and_errors_through_raw_abi(fa):
     assert rc == -1 and b"null" in L.flash_hip_last_error()
     rc = L.flash_fwd_f16(None, None, None, None, 1, 1, 8, 200, 1.0, 11, None)
     assert rc == -2
+    # the scale must be positive and finite (checked before the pointers, on every entry point)
+    for scale in (0.0, -0.125, float("inf"), float("nan")):
+        for fn in (L.flash_fwd_f16, L.flash_fwd_f32, L.flash_fwd_bf16):
+            assert fn(None, None, None, None, 1, 1, 8, 8, scale, 11, None) == -1
+            assert b"softmax_scale" in L.flash_hip_last_error()
 
 
 def test_fp32_workspace_size_query(fa):
