@@ -1,9 +1,9 @@
 // FlashAttention-2 forward for gfx950, head-dim tiles 64 and 128, fp16 rows of a multiple of 8
 // elements, built on v_mfma_f32_16x16x32_f16.
 //
-// Same structure as attn_fwd_mfma.hpp (4 waves, one per SIMD, 64 query rows each; transposed
-// products S^T = K Q^T and O^T = V^T P^T so that a lane owns one query column; K/V in 3-slot LDS
-// rings filled by global->LDS DMA; software pipeline over 32-key blocks with a deferred reference
+// Same structure as attn_fwd_mfma.hpp (transposed products S^T = K Q^T and O^T = V^T P^T so that a
+// lane owns one query column; K/V in 3-slot LDS rings, 4-slot in the persistent kernel, filled by
+// global->LDS DMA; software pipeline over 32-key blocks with a deferred reference
 // update), but with the 16x16x32 MFMA shape instead of 32x32x16.  Under dense MFMA load the chip
 // holds a clock well below nominal and the achieved rate is set by energy per MFMA, not by issue
 // cycles; the 16x16x32 shape moves half as many accumulator registers per FLOP and sustains a
@@ -23,10 +23,10 @@
 //   O^T tile (16 dv x 16 queries): A = V^T with the same key order: two ds_read_b64_tr_b16 (keys
 //     4g.. of rows 0..15 and of rows 16..31 of the block), B = P^T fragment, K = all 32 keys.
 //
-// This file is the body of both wave layouts and is included once per layout by attn_fwd_mfma16.hpp,
+// This file is the body of every wave layout and is included once per layout by attn_fwd_mfma16.hpp,
 // which sets FLASH_M16_NS (the namespace), FLASH_M16_ROWS (query rows per wave) and FLASH_M16_WAVES
-// (64 x 4: one wave per SIMD; 32 x 8: two per SIMD; 128 x 4: one per SIMD, d = 64 only).  Names of the wave geometry declared here shadow the ones
-// of attn_fwd_mfma.hpp inside the namespace.
+// (64 x 4: one wave per SIMD; 32 x 8: two per SIMD; 128 x 4: one per SIMD, d = 64 only).  Names of the
+// wave geometry declared here shadow the ones of attn_fwd_mfma.hpp inside the namespace.
 
 namespace flash_hip {
 namespace FLASH_M16_NS {
