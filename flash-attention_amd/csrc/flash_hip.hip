@@ -282,39 +282,48 @@ int launch_m16p_wide(const FwdParams& prm, hipStream_t stream) {
                        (uint32_t)m16w::kThreads);
 }
 
-// which of the 16x16x32 kernels a whole-row-chunk shape goes to
-static bool routes_persistent(int64_t N) { return N % kBr == 0 && N <= persistent_max_n() && use_persistent(); }
+// Which of the 16x16x32 kernels a whole-row-chunk shape goes to.  Decided once per call (the switches are
+// environment variables that a harness may flip between calls) and handed down, so that the conversion
+// pass and the kernel launch of one call agree.
+enum Route : int {
+  kRouteItem = 0,     // one work item per workgroup (ragged N)
+  kRoutePersistent,   // persistent workgroups, four waves x 64 query rows
+  kRouteWide,         // persistent, eight waves x 32 query rows
+  kRouteTall          // persistent, four waves x 128 query rows (512-row query tiles)
+};
 // fp32 callers (the fp16 kernels with fp32 output): beyond N = 512 they stay on the four-wave layout, whose
 // kernels read Q as fp32 themselves, which is worth more than the eight-wave layout (measured at
 // (4,96,N,128): N = 1024 +5..12 %, N = 512 -1 %)
-static bool routes_wide(const Plan& plan, int64_t N, bool fp32_out) {
-  return routes_persistent(N) && use_wide(plan.tile_d, N) && !(fp32_out && N > 512);
-}
-static bool routes_tall(const Plan& plan, int64_t N) {
-  return routes_persistent(N) && !use_wide(plan.tile_d, N) && use_tall(plan.tile_d, N);
+static Route pick_route(const Plan& plan, int64_t N, bool fp32_out) {
+  if (!(N % kBr == 0 && N <= persistent_max_n() && use_persistent())) return kRouteItem;
+  if (use_wide(plan.tile_d, N)) return (fp32_out && N > 512) ? kRoutePersistent : kRouteWide;
+  return use_tall(plan.tile_d, N) ? kRouteTall : kRoutePersistent;
 }
 
 // fp16 Q, K, V with 16-byte row chunks, O as fp16 or fp32
 template <typename TO>
-int launch_fast(const FwdParams& prm, const Plan& plan, int64_t N, hipStream_t stream) {
+int launch_fast(const FwdParams& prm, const Plan& plan, Route route, hipStream_t stream) {
   static_assert(m16::Cfg<128>::kLdsBytes == Geom<128>::kLdsBytes && m16::Cfg<64>::kLdsBytes == Geom<64>::kLdsBytes,
                 "both kernel families use the same LDS rings");
-  // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
-  // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
-  if (routes_persistent(N)) {
-    if (routes_wide(plan, N, std::is_same<TO, float>::value)) return launch_m16p_wide<TO>(prm, stream);
-    if (routes_tall(plan, N)) {
+  switch (route) {
+    case kRouteWide:
+      return launch_m16p_wide<TO>(prm, stream);
+    case kRouteTall: {
       FwdParams tall = prm;  // the same heads cut into 512-row query tiles
-      tall.nqt = (int)(N / m16x::kBr);
+      tall.nqt = (int)(prm.N / m16x::kBr);
       tall.total_wg = prm.total_wg / (uint32_t)prm.nqt * (uint32_t)tall.nqt;
       static thread_local bool attr_done[16] = {};
       return launch_kernel(m16x::attn_fwd_kernel_m16p<64, typename TallOut<TO>::type>, tall,
                            (uint32_t)m16x::CfgP<64>::kLdsBytes, stream, attr_done, persistent_grid(tall.total_wg),
                            (uint32_t)m16x::kThreads);
     }
-    return plan.tile_d == 64 ? launch_m16p<64, TO>(prm, stream) : launch_m16p<128, TO>(prm, stream);
+    case kRoutePersistent:
+      // Measured launch by launch against the one-item-per-workgroup kernel (selftest ab), B=4 H=96 d=128:
+      // +9 % at N = 512, +8 % at 1024, +4 % at 2048, +2 % at 4096, even at 8192; +5 % at (16,32,2048,64).
+      return plan.tile_d == 64 ? launch_m16p<64, TO>(prm, stream) : launch_m16p<128, TO>(prm, stream);
+    default:
+      return plan.tile_d == 64 ? launch_m16<64, TO>(prm, plan.lds, stream) : launch_m16<128, TO>(prm, plan.lds, stream);
   }
-  return plan.tile_d == 64 ? launch_m16<64, TO>(prm, plan.lds, stream) : launch_m16<128, TO>(prm, plan.lds, stream);
 }
 
 // The fast kernels move 16 bytes per lane (128-bit buffer loads and stores, global->LDS DMA): a tensor
@@ -342,7 +351,8 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
       const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, true);
       return plan.tile_d == 64 ? launch<64, T, true>(prm, plan.lds, stream) : launch<128, T, true>(prm, plan.lds, stream);
 #else
-      return launch_fast<f16>(make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, false), plan, N, stream);
+      return launch_fast<f16>(make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, false), plan,
+                              pick_route(plan, N, false), stream);
 #endif
     }
   }
@@ -374,7 +384,8 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   // K and V, which every query tile of a head re-reads; Q is read by one workgroup per row and the
   // attention kernels take it from the caller's fp32 tensor (m16::kQFromF32), except in the
   // 128-rows-per-wave and eight-wave layouts.  The workspace keeps its three-slot layout (K, V, then Q if converted).
-  const bool cast_q = routes_tall(plan, N) || routes_wide(plan, N, true);
+  const Route route = pick_route(plan, N, true);
+  const bool cast_q = route == kRouteTall || route == kRouteWide;
   const int n_cast = cast_q ? 3 : 2;
   CastParams cp{};
   const void* src[kCastTensors] = {k, v, q};
@@ -391,7 +402,7 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "conversion kernel launch failed: %s", hipGetErrorString(e));
   const FwdParams prm =
       make_params(cast_q ? (const void*)cp.dst[2] : q, cp.dst[0], cp.dst[1], o, B, H, N, d, softmax_scale, plan, false);
-  return launch_fast<float>(prm, plan, N, stream);
+  return launch_fast<float>(prm, plan, route, stream);
 }
 
 // Address of this device's copy of the built-in scratch array.  Every GPU the library runs on holds
@@ -445,7 +456,7 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
   if (!aligned16(q, k, v, o))
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "bfloat16 tensors must be 16-byte aligned");
   const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, false);
-  return launch_fast<m16::bf16_out>(prm, plan, N, (hipStream_t)hip_stream);
+  return launch_fast<m16::bf16_out>(prm, plan, pick_route(plan, N, false), (hipStream_t)hip_stream);
 }
 
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type) {
@@ -498,18 +509,19 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->tile_q = kBr;  // 512 for the 128-rows-per-wave layout, set below
   out->tile_d = (uint32_t)plan.tile_d;
   // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
-  const bool persistent = plan.fast && routes_persistent(N);
+  const Route route = plan.fast ? pick_route(plan, N, entry == FLASH_ENTRY_F32_WS) : kRouteItem;
+  const bool persistent = route != kRouteItem;
   out->lds_bytes = !persistent ? plan.lds
                                : (uint32_t)(plan.tile_d == 64 ? m16::CfgP<64>::kLdsBytes : m16::CfgP<128>::kLdsBytes);
   out->block_x = 64;
-  out->block_y = plan.fast && routes_wide(plan, N, entry == FLASH_ENTRY_F32_WS) ? (uint32_t)m16w::kWaves : (uint32_t)kWaves;
+  out->block_y = route == kRouteWide ? (uint32_t)m16w::kWaves : (uint32_t)kWaves;
   out->grid_x = (uint32_t)B;
   out->grid_y = (uint32_t)H;
   out->grid_z = plan.nqt;
   out->staging = (uint32_t)plan.staging;
   out->aligned_rows = (d % 8 == 0) ? 1u : 0u;
   out->persistent = persistent ? 1u : 0u;
-  if (plan.fast && routes_tall(plan, N)) {
+  if (route == kRouteTall) {
     out->tile_q = (uint32_t)m16x::kBr;
     out->grid_z = (uint32_t)(N / m16x::kBr);
   }
