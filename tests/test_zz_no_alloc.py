@@ -65,3 +65,33 @@ def test_static_scratch_entry_rejects_what_does_not_fit(fa):
     assert L.flash_fwd_f32_workspace_bytes(1, 16, 4096, 128, 11) == 48 << 20
     # errors of the plain entry points are kept
     assert L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 1, 64, 200, 0.1, 11, None) == -2
+
+
+def test_static_scratch_entry_is_capturable_in_a_hip_graph(fa, oracle):
+    """What the entry point is for: recorded into a HIP graph (where hipMalloc is not allowed) after one
+    plain call on the device, which resolves the scratch address and sets the kernels' LDS attribute, and
+    replayed on new data in the same buffers.  Both of its kernels (conversion pass, attention) are in the
+    graph."""
+    import torch
+
+    L = fa.lib()
+    shape = (2, 3, 768, 128)
+    rng = np.random.default_rng(77)
+    host = [rng.standard_normal(shape).astype(np.float32) for _ in range(6)]
+    q, k, v = (torch.from_numpy(x).to("cuda:0") for x in host[:3])
+    o = torch.empty_like(q)
+    assert _call(L, torch, "flash_fwd_f32_static", (q, k, v, o), shape) == 0, L.flash_hip_last_error()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            assert _call(L, torch, "flash_fwd_f32_static", (q, k, v, o), shape) == 0, L.flash_hip_last_error()
+    for base in (0, 3):
+        for t, x in zip((q, k, v), host[base:base + 3]):
+            t.copy_(torch.from_numpy(x).to("cuda:0"))
+        o.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = oracle.attn_naive(*(oracle.round_f16(x) for x in host[base:base + 3]))
+        assert_close(o.cpu().numpy(), ref, f"graph replay of the static-scratch entry, inputs {base}")
