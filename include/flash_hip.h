@@ -147,7 +147,7 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
 /*
  * flash_fwd_f32_ws without the workspace argument, for callers that cannot allocate device memory
  * or hand any over: code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  No counterpart in the reference.  The scratch for the fp16 copies of Q, K and V is a
+ * hipMalloc.  No counterpart in the reference.  The scratch for the fp16 copies of K and V (and of Q where the pass converts it) is a
  * device array built into the library, FLASH_HIP_STATIC_SCRATCH_BYTES (48 MiB) on every GPU the
  * library runs on, held until the process ends.  The call allocates and frees nothing (no hipMalloc,
  * no allocating library routine); it enqueues the same kernels as flash_fwd_f32_ws on `hip_stream`
@@ -159,7 +159,9 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
  * All calls on one GPU share that GPU's buffer: calls that may overlap in time on one GPU (different
  * streams, different threads) race on it and must be serialised by the caller.  Nothing in the
  * buffer needs clearing between calls: every byte a call reads was written by the same call.
- * The buffer's address is looked up once per device, on the first call made with that device current.
+ * The buffer's address is looked up once per device, on the first call made with that device current:
+ * make one plain call per device (and per kernel shape class, which sets the kernels' LDS attribute)
+ * before recording calls into a HIP graph.
  */
 #define FLASH_HIP_STATIC_SCRATCH_BYTES (48ll << 20)
 int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o,
