@@ -629,7 +629,7 @@ struct OutStores<bf16_out> {
 template <typename TO>
 constexpr int kElemKindOf = std::is_same<TO, bf16_out>::value ? kBF16 : kF16;
 
-template <int NB, typename TO>
+template <int NB, typename TO, int AUX = 0>
 __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, uint32_t qrow, int d, int g,
                                               __amdgpu_buffer_rsrc_t o_rs) {
   if constexpr (sizeof(TO) == 2) {
@@ -650,7 +650,7 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
       }
       const int dv = 16 * (b + (g & 1)) + 8 * (g >> 1);
       const uint32_t off = (dv < d) ? (qrow * (uint32_t)d + (uint32_t)dv) * 2u : kOob;
-      __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(out, o_rs, off, 0, AUX);
     }
   } else {
 #pragma unroll
@@ -660,7 +660,7 @@ __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, 
       for (int j = 0; j < 4; ++j) x[j] = oq[b][j] * inv;
       const int dv = 16 * b + 4 * g;
       const uint32_t off = (dv < d) ? (qrow * (uint32_t)d + (uint32_t)dv) * 4u : kOob;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), o_rs, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x), o_rs, off, 0, AUX);
     }
   }
 }
@@ -1031,6 +1031,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   auto head_of = [&](uint32_t it) __attribute__((always_inline)) { return it / (uint32_t)p.nqt; };
   constexpr bool QF32 = kQFromF32<TO>;
   constexpr uint32_t kQElem = QF32 ? 4u : 2u;
+  // Cache policy of the output stores.  O is written once and never read back: in the long-sequence
+  // d = 128 kernel the stores go through to memory (sc0 sc1 nt), so that O lines neither sit dirty in the
+  // L2 that serves the K/V re-reads nor wait for the flush at the kernel's end: +0.3 % at (4,96,4096,128),
+  // +1 % at (8,96,4096,128), +0.7 % at N = 8192.  Short sequences and d = 64 measured 1 % slower with it.
+  constexpr int kOutAux = (D == 128 && kQ16 == 4) ? 19 : 0;
 
   // per-lane byte offsets of the Q chunks inside a head, for query tile 0 (a tile adds kBr rows)
   uint32_t q_off[kQ16][kKS];
@@ -1297,7 +1302,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       }
       const float inv = __builtin_amdgcn_rcpf(quad_lane_sum(lsum[q][0], lane));  // v_rcp_f32, 1 ulp
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
-      store_o_block<kDv16, TO>(o[q], inv, qrow, d, g, o_rs);
+      store_o_block<kDv16, TO, kOutAux>(o[q], inv, qrow, d, g, o_rs);
     }
 #if defined(FLASH_PHASE_STAMPS)
     if (!has_next) {
