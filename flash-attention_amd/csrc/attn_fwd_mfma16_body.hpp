@@ -1034,7 +1034,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   // Cache policy of the output stores.  O is written once and never read back: in the long-sequence
   // d = 128 kernel the stores go through to memory (sc0 sc1 nt), so that O lines neither sit dirty in the
   // L2 that serves the K/V re-reads nor wait for the flush at the kernel's end: +0.3 % at (4,96,4096,128),
-  // +1 % at (8,96,4096,128), +0.7 % at N = 8192.  Short sequences and d = 64 measured 1 % slower with it.
+  // +1 % at (8,96,4096,128), +0.7 % at N = 8192 in the four-wave layout.  Short sequences and d = 64
+  // measured 1 % slower with it, the eight-wave layout the same with and without.
   constexpr int kOutAux = (D == 128 && kQ16 == 4) ? 19 : 0;
 
   // per-lane byte offsets of the Q chunks inside a head, for query tile 0 (a tile adds kBr rows)

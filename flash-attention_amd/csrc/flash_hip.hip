@@ -228,14 +228,17 @@ static uint32_t persistent_grid(uint32_t items) {
   return items < g ? items : (g ? g : 8u);
 }
 
-// Sequences up to this length run the persistent d = 128 kernel in the eight-wave layout (two waves per
-// SIMD, 32 query rows each): the two waves of a SIMD fill each other's matrix-pipe gaps at the item
-// boundaries, which is what short items are made of.  Longer sequences measure the same in both
-// layouts and keep the four-wave one (half the LDS reads).  d = 64 gains nothing from it at any length.
-// FLASH_HIP_WIDE_MAX_N overrides the limit (A/B measurements; read on every call).
+// Whole-tile d = 128 shapes run the persistent kernel in the eight-wave layout (two waves per SIMD, 32
+// query rows each).  The two waves of a SIMD fill each other's matrix-pipe gaps: at the item boundaries,
+// which is what short items are made of (+9 % at N = 512, +3 % at 1024), and inside the steps, where one
+// wave alone is issue-bound.  On long sequences the saved cycles (10 %) come back as a lower clock on
+// boxes that sit at the power cap (same time) and as time on the others: measured +0.2 %, +0.9 %, +1.3 %,
+// +4.2 % at (8,96,4096,128) on four boxes, +4 % at N = 8192 and 16384 on the slowest, never slower than
+// within noise.  d = 64 gains nothing from it at any length.  FLASH_HIP_WIDE_MAX_N=<n> limits the layout
+// to sequences up to n (0 = never; A/B measurements; read on every call).
 static int64_t wide_max_n() {
   const char* e = getenv("FLASH_HIP_WIDE_MAX_N");
-  return e ? atoll(e) : 2048;
+  return e ? atoll(e) : (int64_t)1 << 40;
 }
 static bool use_wide(int tile_d, int64_t N) { return tile_d == 128 && N <= wide_max_n(); }
 

@@ -28,7 +28,8 @@ class KernelParametersBase {
 };
 
 // Geometry of the wave64 MFMA kernel: 256 query rows per workgroup (Br), worked by 4 waves (one per
-// SIMD) x 64 rows or, for whole-tile d = 128 shapes up to N = 2048, by 8 waves x 32 rows; 64-row K/V
+// SIMD) x 64 rows or, for whole-tile d = 128 shapes, by 8 waves x 32 rows (512 rows, 4 waves x 128, for
+// whole 512-row tiles of d <= 64); 64-row K/V
 // tiles (Bc), head dim padded to 64 or 128, rings of three (persistent kernel: four) K and as many V
 // tiles in LDS.  The numbers come from the library (flash_fwd_query), not from this header.
 // Replaces MMAQregParameters / MMAQregAsyncParameters (reference flash/KernelParameters.hpp:332-381).

@@ -65,7 +65,7 @@ typedef struct flash_launch_info {
   uint32_t tile_d;       /* head dim padded to the compiled tile     (tileSize().z) */
   uint32_t lds_bytes;    /* dynamic LDS per workgroup                (sramSize())   */
   uint32_t block_x;      /* lanes per wave = 64                      (blockDim().x) */
-  uint32_t block_y;      /* waves per workgroup: 4, or 8 for whole-tile d > 64 shapes up to N = 2048 (blockDim().y) */
+  uint32_t block_y;      /* waves per workgroup: 4, or 8 for whole-tile shapes with d > 64 (blockDim().y) */
   uint32_t grid_x;       /* B                                        (gridDim().x)  */
   uint32_t grid_y;       /* H                                        (gridDim().y)  */
   uint32_t grid_z;       /* ceil(N / Br): grid = the work items; when N % Br == 0 a persistent kernel

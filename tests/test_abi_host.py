@@ -33,18 +33,17 @@ def test_kernel_type_names_match_reference_order(fa):
 
 
 def test_geometry_query(fa):
-    # GPT-3 head shape: 16 query tiles of 256 rows, 4 waves of 64 lanes (one per SIMD); whole tiles run on
-    # the persistent kernel: 4 K + 4 V tiles of 64 x 128 halves = 128 KiB of LDS
+    # GPT-3 head shape: 16 query tiles of 256 rows, worked by 8 waves of 64 lanes x 32 query rows (two per
+    # SIMD); whole tiles run on the persistent kernel: 4 K + 4 V tiles of 64 x 128 halves = 128 KiB of LDS
     info = fa.launch_info(4, 96, 4096, 128, fa.KernelType.mma_qreg_async)
     assert info.tile_size == (64, 256, 128)
-    assert info.block_dim == (64, 4)
+    assert info.block_dim == (64, 8)
     assert info.grid_dim == (4, 96, 16)
     assert info.sram_size == 131072 and info.sram_size <= 160 * 1024
-    assert info.staging == 2 and info.aligned_rows
-    # up to N = 2048 the same tile is worked by 8 waves of 32 query rows (two per SIMD)
-    info = fa.launch_info(4, 96, 2048, 128, fa.KernelType.mma_qreg_async)
-    assert info.tile_size == (64, 256, 128) and info.block_dim == (64, 8) and info.grid_dim == (4, 96, 8)
-    assert info.sram_size == 131072 and info.persistent
+    assert info.staging == 2 and info.aligned_rows and info.persistent
+    # ragged N: one item per workgroup, 4 waves x 64 query rows, three-slot rings
+    info = fa.launch_info(4, 96, 4000, 128, fa.KernelType.mma_qreg_async)
+    assert info.block_dim == (64, 4) and info.grid_dim == (4, 96, 16) and not info.persistent
     # small heads keep four waves; whole 512-row tiles give every wave 128 query rows (tile_q 512)
     info = fa.launch_info(16, 32, 2048, 64)
     assert info.block_dim == (64, 4) and info.tile_size == (64, 512, 64) and info.grid_dim == (16, 32, 4)
