@@ -17,7 +17,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "ceiling")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 FLOPS = 4.0 * 8 * 96 * 4096 * 4096 * 128
 
-KNOCK = {0: "nothing (the shipped kernel)", 1: "exponentials", 2: "K/V staging (global -> LDS)", 4: "LDS fragment reads",
+KNOCK = {0: "nothing (the shipped kernel, eight-wave layout)", 1: "exponentials", 2: "K/V staging (global -> LDS)", 4: "LDS fragment reads",
          8: "conversion of P to fp16", 16: "row sums", 32: "running maximum", 64: "score multiply",
          127: "all of the above (matrix instructions and barriers only)"}
 
@@ -66,8 +66,10 @@ out = {
                  "--pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace pass each; FLASH_HIP_WIDE_MAX_N picks the wave layout)"],
     "wave_layouts": layouts,
     "wave_layouts_reading": "the eight-wave layout needs about a tenth fewer cycles for the same launch and the chip "
-                            "answers with a clock about a tenth lower: the launch takes the same time.  Under this "
-                            "kernel the chip is limited by power, not by issue slots.",
+                            "answers with a clock about a tenth lower: on a box at its power cap the launch takes "
+                            "about the same time (within 1-2 %).  Under this kernel the chip is limited by power, "
+                            "not by issue slots.  (Boxes that hold their clock turn the saved cycles into time: up "
+                            "to +4 % was measured for the eight-wave layout.)",
     "knockouts": knock,
     "knockouts_reading": "timing only, results are wrong.  Builds that freeze matrix operands (4, 8, 64, 127: stale "
                          "fragments, constant or saturated P) also lower the switching activity of the matrix pipe "
