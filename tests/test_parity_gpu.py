@@ -158,18 +158,39 @@ def test_seeded_fuzz_over_shapes_types_and_entry_points(fa, oracle, torch_gpu):
         done += 1
 
 
-def test_forced_rescale_spike(fa, oracle, torch_gpu):
+def test_forced_rescale_spike(fa, oracle, torch_gpu, monkeypatch):
     """A key that dominates a query row late in the sweep forces the online-softmax rescale (the
-    running max jumps by far more than any deferral threshold) at chosen tiles."""
-    B, H, N, d = 1, 2, 640, 128
-    rng = np.random.default_rng(7)
-    q, k, v = (rng.standard_normal((B, H, N, d)).astype(np.float32) for _ in range(3))
-    for (row, key, gain) in [(5, 200, 6.0), (37, 449, 9.0), (300, 639, 12.0), (301, 64, 8.0), (599, 3, 7.0)]:
-        k[0, :, key] = gain * q[0, :, row] / np.linalg.norm(q[0, :, row], axis=-1, keepdims=True)
-    q, k, v = (oracle.round_f16(x) for x in (q, k, v))
-    ref = oracle.attn_naive(q, k, v)
-    o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float16)
-    assert_close(o, ref, "spiked keys")
+    running max jumps by far more than any deferral threshold) at chosen tiles.  Run through every
+    kernel the library has: one item per workgroup (ragged N), and the persistent kernel in its three
+    wave layouts, with more work items than workgroups at the last shapes (the rescale state must not
+    leak from one item into the next)."""
+    cases = [
+        ((1, 2, 640, 128), {}),                                   # ragged: one item per workgroup
+        ((1, 3, 768, 128), {}),                                   # persistent, eight waves x 32 rows
+        ((1, 3, 768, 128), {"FLASH_HIP_WIDE_MAX_N": "0"}),        # persistent, four waves x 64 rows
+        ((1, 3, 768, 64), {}),                                    # persistent d = 64, 256-row tiles
+        ((1, 3, 1024, 64), {}),                                   # persistent d = 64, 512-row tiles
+        ((2, 150, 768, 128), {}),                                 # 900 items on 256 workgroups
+        ((2, 150, 768, 128), {"FLASH_HIP_WIDE_MAX_N": "0"}),
+        ((2, 300, 1024, 64), {}),                                 # 1200 items of 512 rows
+    ]
+    for shape, env in cases:
+        B, H, N, d = shape
+        for name, val in env.items():
+            monkeypatch.setenv(name, val)
+        rng = np.random.default_rng(7)
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+        spikes = [(5, 200, 6.0), (37, 449, 9.0), (300, N - 1, 12.0), (301, 64, 8.0), (N - 41, 3, 7.0), (N - 1, N - 2, 10.0)]
+        for (row, key, gain) in spikes:
+            k[:, :, key] = gain * q[:, :, row] / np.linalg.norm(q[:, :, row], axis=-1, keepdims=True)
+        q, k, v = (oracle.round_f16(x) for x in (q, k, v))
+        o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float16)
+        heads = sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2), (0, min(H - 1, 1))})
+        for (b, h) in heads:
+            ref = oracle.attn_naive(*(x[b:b + 1, h:h + 1] for x in (q, k, v)))[0, 0]
+            assert_close(o[b, h], ref, f"spiked keys {shape} {env} head {(b, h)}")
+        for name in env:
+            monkeypatch.delenv(name)
 
 
 def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
@@ -181,8 +202,8 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
     an argmax whose near-ties amplify the fp32 rounding of the scores themselves (one part in 10^7 of a
     score of several hundred moves a weight by 10^-4), so a small share of rows may sit just above the
     bar; none may be far off."""
-    B, H, N = 1, 1, 384
-    for d in (64, 128):
+    B, H = 1, 1
+    for N, d in ((384, 64), (384, 128), (512, 64), (512, 128)):   # ragged and persistent kernels
         rng = np.random.default_rng(11 + d)
         q = (rng.standard_normal((B, H, N, d)) * 8).astype(np.float32)
         k = (rng.standard_normal((B, H, N, d)) * 8).astype(np.float32)
@@ -191,9 +212,9 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
         o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float16)
         assert np.isfinite(o).all()
         err_rows = np.abs(o - oracle.attn_numpy(q, k, v)).max(axis=-1)
-        print(f"large scores d={d}: {(err_rows > ATOL).mean():.3f} of the rows above {ATOL}, max {err_rows.max():.3e}")
+        print(f"large scores N={N} d={d}: {(err_rows > ATOL).mean():.3f} of the rows above {ATOL}, max {err_rows.max():.3e}")
         assert (err_rows > ATOL).mean() <= 0.02 and err_rows.max() <= 1e-2, (
-            f"d={d}: {(err_rows > ATOL).mean():.3f} of the rows off, max {err_rows.max():.3e}")
+            f"N={N} d={d}: {(err_rows > ATOL).mean():.3f} of the rows off, max {err_rows.max():.3e}")
 
 
 def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monkeypatch):
