@@ -100,6 +100,23 @@ def test_seeded_shapes_vs_oracle(fa, oracle, torch_gpu, shape):
     assert_close(o, ref, f"{shape} fp32 with workspace")
 
 
+def test_fp32_callers_many_items_per_workgroup(fa, oracle, torch_gpu):
+    """fp32 tensors through the workspace with more work items than workgroups: the persistent kernels
+    fetch the next item's Q as fp32 during the current item's epilogue (two landing phases at d = 128,
+    one at d = 64) and convert it behind the output stores; inputs that are not fp16-representable, so
+    the in-kernel rounding of Q is what is checked.  The 512-row-tile and N <= 512 shapes take Q from
+    the conversion pass instead."""
+    torch = torch_gpu
+    for shape in ((2, 150, 768, 128), (2, 300, 768, 64), (2, 300, 1024, 64), (3, 200, 512, 128)):
+        rng = np.random.default_rng(shape[1] + shape[2])
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.21) for _ in range(3))
+        o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32, workspace=True)
+        B, H = shape[:2]
+        for (b, h) in sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2), (0, 1), (B - 1, H - 2)}):
+            ref = oracle.attn_naive(*(oracle.round_f16(x[b:b + 1, h:h + 1]) for x in (q, k, v)))[0, 0]
+            assert_close(o[b, h], ref, f"fp32 through workspace {shape} head {(b, h)}")
+
+
 def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gpu):
     """fp32 tensors that are NOT fp16-representable: the conversion pass into the workspace and the
     in-kernel conversion round the same way (to nearest even), so both agree with the oracle on the
