@@ -3,7 +3,7 @@
 Not part of the reference (its tensors are fp32).  Bar, stated here because bfloat16 keeps 8 mantissa
 bits where fp16 keeps 11: against the fp32 CPU oracle evaluated on the bfloat16-rounded inputs,
 max-abs <= 1.6e-2 and |res - ref| <= 1.6e-2 + 2e-2 |ref| (eight times the fp16 bar, for the three mantissa
-bits less; P, Q * scale and O are rounded to bfloat16).  Measured on standard-normal data: 1e-3 ... 4.4e-3
+bits less; P and O are rounded to bfloat16).  Measured on standard-normal data: 1e-3 ... 4.4e-3
 on the shapes below, 7.4e-3 worst over a few hundred random shapes.
 """
 import ctypes
@@ -67,6 +67,26 @@ def test_bf16_forced_rescale_and_wrapper(fa, oracle):
     t = torch.zeros((1, 1, 16, 12), device="cuda", dtype=torch.bfloat16)
     with pytest.raises(ValueError, match="multiple of 8"):
         fa.forward(t, t, t, fa.KernelType.mma)
+
+
+def test_bf16_many_items_per_workgroup_with_spikes(fa, oracle):
+    """More work items than workgroups in each persistent layout the bfloat16 kernels have (eight waves at
+    d = 128, 512-row tiles and 256-row tiles at d = 64), with keys that force the rescale path."""
+    import torch
+
+    for shape in ((2, 150, 768, 128), (2, 300, 1024, 64), (2, 300, 768, 64)):
+        B, H, N, d = shape
+        rng = np.random.default_rng(N + d)
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+        for (row, key, gain) in [(5, 200, 6.0), (300, N - 1, 10.0), (N - 1, 64, 8.0)]:
+            k[:, :, key] = gain * q[:, :, row] / np.linalg.norm(q[:, :, row], axis=-1, keepdims=True)
+        q, k, v = (oracle.round_bf16(x) for x in (q, k, v))
+        o = run_bf16(fa, torch, q, k, v)
+        assert not np.isnan(o).any()
+        for (b, h) in sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2), (0, 1)}):
+            ref = oracle.attn_naive(*(x[b:b + 1, h:h + 1] for x in (q, k, v)))[0, 0]
+            err = np.abs(o[b, h] - ref)
+            assert err.max() <= ATOL_BF16 and (err <= ATOL_BF16 + RTOL_BF16 * np.abs(ref)).all(), (shape, b, h, err.max())
 
 
 def test_bf16_through_the_torch_op(fa, oracle):
