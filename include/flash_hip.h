@@ -129,9 +129,10 @@ int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
  * fp32 attention forward with a caller-provided workspace: the fast path for the same fp32 callers
  * (reference main.cpp:30-32, benchmarks/bench.py:34-36, flash/launch.cu:165-176; the reference
  * itself allocates per-call scratch for its non-register kernels, launch.cu:150-157).
- * When d % 8 == 0 one streaming pass rounds Q, K and V to fp16 (round-to-nearest-even, the rounding
- * flash_fwd_f32 applies) into `workspace`, and the fp16 kernels of flash_fwd_f16 run on that copy,
- * writing O as fp32 straight from the accumulators.  Same results as flash_fwd_f32 up to the order of
+ * When d % 8 == 0 one streaming pass rounds K and V to fp16 (round-to-nearest-even, the rounding
+ * flash_fwd_f32 applies) into `workspace`, and the fp16 kernels of flash_fwd_f16 run on those copies,
+ * reading Q from the caller's fp32 tensor (rounded the same way on its way into the registers; two of
+ * the wave layouts take Q from the pass as well) and writing O as fp32 straight from the accumulators.  Same results as flash_fwd_f32 up to the order of
  * fp32 additions; about three times its throughput at long sequences, because every K/V element is
  * converted once instead of once per workgroup that reads it.
  * `workspace`: device memory, 16-byte aligned, at least flash_fwd_f32_workspace_bytes(...) bytes;

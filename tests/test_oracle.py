@@ -111,8 +111,8 @@ def test_error_split_p_rounding_vs_q_prescale(oracle, sigma):
     """Where the fp16 kernel's error comes from, on the CPU model of its loop (Br=256, Bc=64, fp16 P,
     normalise once): the fp16 rounding of P alone, against P plus a fp16 rounding of
     Q * scale * log2(e).  The second is the larger share by far and grows with the input scale, which
-    is why the kernel applies only the power-of-two part of the scale to Q (exact in fp16) and the
-    remaining factor to the fp32 scores."""
+    is why the kernel leaves Q as the caller stored it and applies the whole factor to the fp32
+    scores."""
     rng = np.random.default_rng(11)
     q, k, v = (oracle.round_f16(rng.standard_normal((1, 4, 512, 128)).astype(np.float32) * sigma) for _ in range(3))
     ref = oracle.attn_naive(q, k, v)

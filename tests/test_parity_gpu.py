@@ -214,7 +214,7 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
     """Scores with a standard deviation of ~90 in exp2 units (|q.k|/sqrt(d) of several hundred): the
     exp2 domain must stay finite and the reference updates must keep up.
 
-    Q reaches the matrix cores exactly (only the power-of-two part of the scale is applied to it), so the
+    Q reaches the matrix cores exactly (the scale is applied to the fp32 scores), so the
     result is compared with the unperturbed oracle, evaluated in float64.  At this spread the softmax is
     an argmax whose near-ties amplify the fp32 rounding of the scores themselves (one part in 10^7 of a
     score of several hundred moves a weight by 10^-4), so a small share of rows may sit just above the
