@@ -71,7 +71,7 @@ ABI_SYMBOLS = (
     "flash_fwd_f32_workspace_bytes", "flash_fwd_query",
     "flash_fwd_query_entry",
     "flash_kernel_type_name",
-    "flash_hip_last_error", "flash_hip_version",
+    "flash_hip_last_error", "flash_hip_version", "flash_hip_reload_switches",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -110,6 +110,8 @@ def lib() -> ctypes.CDLL:
     L.flash_hip_last_error.restype = ctypes.c_char_p
     L.flash_hip_version.argtypes = []
     L.flash_hip_version.restype = ctypes.c_int
+    L.flash_hip_reload_switches.argtypes = []
+    L.flash_hip_reload_switches.restype = ctypes.c_int
     _lib = L
     return L
 

@@ -232,6 +232,19 @@ __device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
   return r;
 }
 
+// The memory instructions below are issued from inline asm, so the compiler provides none of the wait
+// states their scalar operands need: a vector memory instruction must not read a scalar register within
+// five wait states of a VECTOR instruction writing it (v_readfirstlane: make_srd, wave-uniform offsets the
+// compiler keeps in vector registers when scalar registers run short).  Call this on such operands where
+// they may be fresh: it holds the values in scalar registers at this point of the program (the compiler
+// cannot sink their computation below it) and spends the wait states.  tests/test_kernel_asm.py checks the
+// generated code for the hazard.
+__device__ __forceinline__ void settle_scalars(srd_t& a) { asm volatile("s_nop 4" : "+s"(a)); }
+__device__ __forceinline__ void settle_scalars(srd_t& a, srd_t& b) { asm volatile("s_nop 4" : "+s"(a), "+s"(b)); }
+__device__ __forceinline__ void settle_scalars(srd_t& a, srd_t& b, uint32_t& c, uint32_t& d) {
+  asm volatile("s_nop 4" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+}
+
 // One direct global->LDS piece: every lane moves 16 bytes from byte offset `voff` of the buffer to
 // LDS address lds_base + 16*lane (1 KiB per wave-instruction).  Issued from inline asm on purpose:
 // the compiler does not see the load, so it neither waits for it before unrelated ds_reads nor

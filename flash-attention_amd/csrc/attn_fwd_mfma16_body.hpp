@@ -685,7 +685,11 @@ __device__ __forceinline__ f16x8 q_frag_from_f32(const u32x4& lo, const u32x4& h
   return __builtin_bit_cast(f16x8, w);
 }
 
-template <int D, typename TO = f16>
+// KV32: K and V are the caller's fp32 tensors as well (TO = float, Q read as fp32 too): every wave loads
+// its share of a tile with 128-bit loads, rounds it to fp16 (nearest even) and writes the swizzled LDS
+// image itself, where the fp16 kernels let the global->LDS DMA do it.  No conversion pass, no workspace:
+// the route of fp32 callers whose K/V rows have few readers (short sequences) or who bring no scratch.
+template <int D, typename TO = f16, bool KV32 = false>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = Cfg<D>;
@@ -714,38 +718,57 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
   constexpr bool QF32 = kQFromF32<TO>;
+  static_assert(!KV32 || QF32, "fp32 K and V come with fp32 Q and fp32 O (four-wave layout)");
   constexpr uint32_t kQElem = QF32 ? 4u : 2u;
+  constexpr uint32_t kKVElem = KV32 ? 4u : 2u;
   const char* qh = (const char*)p.q + (size_t)head * head_elems * kQElem;
-  const f16* kh = (const f16*)p.k + (size_t)head * head_elems;
-  const f16* vh = (const f16*)p.v + (size_t)head * head_elems;
+  const char* kh = (const char*)p.k + (size_t)head * head_elems * kKVElem;
+  const char* vh = (const char*)p.v + (size_t)head * head_elems * kKVElem;
   TO* oh = (TO*)p.o + (size_t)head * head_elems;
   const __amdgpu_buffer_rsrc_t q_rs =
       __builtin_amdgcn_make_buffer_rsrc((void*)qh, 0, (uint32_t)(head_elems * kQElem), 0x00020000);
   const __amdgpu_buffer_rsrc_t o_rs =
       __builtin_amdgcn_make_buffer_rsrc((void*)oh, 0, (uint32_t)(head_elems * sizeof(TO)), 0x00020000);
-  const srd_t k_srd = make_srd(kh, head_bytes);
-  const srd_t v_srd = make_srd(vh, head_bytes);
+  const srd_t k_srd = make_srd(kh, head_bytes * (kKVElem / 2u));
+  const srd_t v_srd = make_srd(vh, head_bytes * (kKVElem / 2u));
 
-  const uint32_t row_bytes = (uint32_t)d * 2u;
+  const uint32_t row_bytes = (uint32_t)d * kKVElem;
   const uint32_t tile_step = (uint32_t)kBc * row_bytes;
 
   lds_char* const k_ring = smem;
   lds_char* const v_ring = smem + kRing * kTileBytes;
 
   // staging: piece pc = 1 KiB of consecutive LDS chunks; lane i of it fills chunk (64 pc + i) % kChunks
-  // of row (64 pc + i) / kChunks with the source chunk that the swizzle maps there
+  // of row (64 pc + i) / kChunks with the source chunk that the swizzle maps there (8 elements: 16 bytes
+  // of an fp16 row, 32 bytes of an fp32 row)
   uint32_t dma_off[kPiecesPerWave];
 #pragma unroll
   for (int i = 0; i < kPiecesPerWave; ++i) {
     const int ci = (wave * kPiecesPerWave + i) * 64 + lane;
     const int row = ci / C::kChunks;
     const int src = (ci % C::kChunks) ^ swz<D>(row);
-    dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
+    dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 8u * kKVElem : kOob;
   }
   auto piece = [&](const srd_t srd, lds_char* ring, int slot, int t, int i) __attribute__((always_inline)) {
     const int pc = wave * kPiecesPerWave + i;
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + slot * kTileBytes + pc * 1024));
     dma_piece(srd, dma_off[i] + (uint32_t)t * tile_step, lds_base);
+  };
+  // fp32 K/V: the two halves of piece i's chunk land in registers (the compiler tracks these loads and
+  // waits for them where they are converted), ...
+  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kh, 0, head_bytes * (kKVElem / 2u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vh, 0, head_bytes * (kKVElem / 2u), 0x00020000);
+  u32x4 land[KV32 ? kPiecesPerWave : 1][2];
+  auto load_piece = [&](const __amdgpu_buffer_rsrc_t rs, int t, int i) __attribute__((always_inline)) {
+    // (an out-of-range chunk keeps an out-of-range offset: kOob plus a tile offset stays below 2^31)
+    const uint32_t off = dma_off[i] + (uint32_t)t * tile_step;
+    land[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    land[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, 0);
+  };
+  // ... and are written, rounded to fp16, to the place the DMA would have filled
+  const uint32_t lds_lane = (uint32_t)(wave * kPiecesPerWave * 1024 + lane * 16);
+  auto write_piece = [&](lds_char* ring, int slot, int i) __attribute__((always_inline)) {
+    *FLASH_LDS_CAST(f16x8, ring + slot * kTileBytes + i * 1024 + lds_lane) = q_frag_from_f32(land[i][0], land[i][1]);
   };
   auto stage = [&](const srd_t srd, lds_char* ring, int slot, int t) __attribute__((always_inline)) {
 #pragma unroll
@@ -777,9 +800,33 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       }
     }
   }
-  stage(k_srd, k_ring, 0, 0);
-  stage(v_srd, v_ring, 0, 0);
-  if (nt > 1) stage(k_srd, k_ring, 1, 1);
+  if constexpr (KV32) {
+    // all three tiles' loads in flight at once (the score and probability registers are still free):
+    // one memory round trip for the cold start instead of three.  Tile 1 of a one-tile sequence lies
+    // beyond the head: its loads return zeros.
+    u32x4 cold[3][kPiecesPerWave][2];
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int i = 0; i < kPiecesPerWave; ++i) {
+        const uint32_t off = dma_off[i] + (w == 2 ? tile_step : 0u);
+        cold[w][i][0] = __builtin_amdgcn_raw_buffer_load_b128(w == 1 ? v_rs : k_rs, off, 0, 0);
+        cold[w][i][1] = __builtin_amdgcn_raw_buffer_load_b128(w == 1 ? v_rs : k_rs, off + 16u, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+      for (int i = 0; i < kPiecesPerWave; ++i) {
+        *FLASH_LDS_CAST(f16x8, (w == 1 ? v_ring : k_ring) + (w == 2 ? kTileBytes : 0) + i * 1024 + lds_lane) =
+            q_frag_from_f32(cold[w][i][0], cold[w][i][1]);
+      }
+    }
+  } else {
+    stage(k_srd, k_ring, 0, 0);
+    stage(v_srd, v_ring, 0, 0);
+    if (nt > 1) stage(k_srd, k_ring, 1, 1);
+  }
   // Step 0 multiplies P(-1) = 0 with the second block of "V tile -1" (slot 2): make that finite.
   for (int i = tid * 16; i < kBlkBytes; i += kThreads * 16) {
     *FLASH_LDS_CAST(u32x4, v_ring + 2 * kTileBytes + kBlkBytes + i) = u32x4{0u, 0u, 0u, 0u};
@@ -864,7 +911,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const int s0 = SLOT >= 0 ? SLOT : slot_rt;
     const int s1 = s0 == 2 ? 0 : s0 + 1;
     const int s2 = s1 == 2 ? 0 : s1 + 1;
-    auto no_hook = [](int) __attribute__((always_inline)) {};
     // staging spread over the slots of the first step: K tile t+2, then V tile t+1
     auto dma_hook = [&](int n) __attribute__((always_inline)) {
       constexpr int kSpacing = (2 * kKS + kDv16) * kQ16 / (2 * kPiecesPerWave);
@@ -877,14 +923,38 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
         }
       }
     };
+    // fp32 K/V: one tile per step, K tile t+2 in the first and V tile t+1 in the second.  Its loads go out
+    // in the step's first slots and are converted and written in its last ones, a step's worth of matrix
+    // work (about a microsecond) later.  Both targets are slots nobody reads in this iteration.
+    auto vec_hook = [&](int n, bool v_side) __attribute__((always_inline)) {
+      constexpr int kSlots = (2 * kKS + kDv16) * kQ16;
+      constexpr int kFirstWrite = kSlots - 2 * kPiecesPerWave - 2;
+      const bool go = !MASKED || (v_side ? t + 1 < nt : t + 2 < nt);  // the unmasked iterations always stage
+      if (n >= 1 && n < 1 + 2 * kPiecesPerWave && (n - 1) % 2 == 0) {
+        if (go) load_piece(v_side ? v_rs : k_rs, v_side ? t + 1 : t + 2, (n - 1) / 2);
+      }
+      if (n >= kFirstWrite && n < kFirstWrite + 2 * kPiecesPerWave && (n - kFirstWrite) % 2 == 0) {
+        if (go) write_piece(v_side ? v_ring : k_ring, v_side ? s1 : s2, (n - kFirstWrite) / 2);
+      }
+    };
+    auto hook1 = [&](int n) __attribute__((always_inline)) {
+      if constexpr (KV32) {
+        vec_hook(n, false);
+      } else {
+        dma_hook(n);
+      }
+    };
+    auto hook2 = [&](int n) __attribute__((always_inline)) {
+      if constexpr (KV32) vec_hook(n, true);
+    };
     const uint32_t k_cur = (uint32_t)(s0 * kTileBytes);
     const uint32_t k_nxt = (uint32_t)(s1 * kTileBytes);
     const uint32_t v_cur = (uint32_t)(s0 * kTileBytes);
     const uint32_t v_prv = (uint32_t)(s2 * kTileBytes);
-    pipeline_step<D, true, !LAST, MASKED, kPvAccumulate, EK>(dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
+    pipeline_step<D, true, !LAST, MASKED, kPvAccumulate, EK>(hook1, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB,
                                        pB, pA, mx_all, lsum, sc, pending, vote, t * kBc + 32, N, lane);
     step_end<kDv16, true>(o, st, mx_all, lsum, bias, sB, pending, vote, sc, lane);
-    pipeline_step<D, !LAST, !LAST, MASKED, kPvAccumulate, EK>(no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all,
+    pipeline_step<D, !LAST, !LAST, MASKED, kPvAccumulate, EK>(hook2, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all,
                                         lsum, sc, pending, vote, (t + 1) * kBc, N, lane);
     step_end<kDv16, !LAST>(o, st, mx_all, lsum, bias, sA, pending, vote, sc, lane);
     staged_barrier();
@@ -967,7 +1037,9 @@ __device__ __forceinline__ void wait_q(f16x8 (&qf)[kQ16][KS]) {
   }
 }
 
-template <int D, typename TO = f16>
+// KV32: as in attn_fwd_kernel_m16, K and V are the caller's fp32 tensors and every wave converts its share
+// of a tile on its way into LDS (TO = float, four-wave layout).
+template <int D, typename TO = f16, bool KV32 = false>
 __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using C = CfgP<D>;
@@ -1001,7 +1073,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
-  const uint32_t row_bytes = (uint32_t)d * 2u;
+  constexpr uint32_t kKVElem = KV32 ? 4u : 2u;
+  static_assert(!KV32 || (std::is_same<TO, float>::value && kQ16 <= 4),
+                "fp32 K and V come with fp32 Q and fp32 O (four- and eight-wave layouts)");
+  const uint32_t row_bytes = (uint32_t)d * kKVElem;
   const uint32_t tile_step = (uint32_t)kBc * row_bytes;
 
   lds_char* const k_ring = smem;
@@ -1013,23 +1088,72 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const int ci = (wave * kPiecesPerWave + i) * 64 + lane;
     const int row = ci / C::kChunks;
     const int src = (ci % C::kChunks) ^ swz<D>(row);
-    dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 16u : kOob;
+    dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 8u * kKVElem : kOob;
   }
+  // fp32 K/V: the two halves of piece i's chunk land in registers and are rounded to fp16 and written to
+  // the place the DMA would have filled.  Where the loop leaves vector registers free (d = 64) these are
+  // ordinary loads: the compiler tracks them and waits where they are converted.  In the d = 128 kernels
+  // the vector registers are all taken: there the loads land in ACCUMULATION registers (32 of the 48 that
+  // O^T, Q and the row sums leave free in the four-wave layout, 16 of 21 in the eight-wave layout, whose
+  // waves stage half as much each), issued from inline asm, which the compiler neither sees nor waits for: write_piece waits
+  // itself, counting the younger loads of the same tile (vector memory operations complete in order), and
+  // the values pass through v_accvgpr_read on their way to the conversion.
+  constexpr bool kLandAcc = KV32 && D == 128;
+  auto kv_srd = [&](const void* base, uint32_t hd) __attribute__((always_inline)) {
+    return make_srd((const char*)base + (size_t)hd * head_elems * kKVElem, head_bytes * (kKVElem / 2u));
+  };
+  u32x4 land[KV32 ? kPiecesPerWave : 1][2];
+  // Tile t of the head behind `srd`.  Whole tiles only: the tile offset bypasses the range check as a scalar
+  // offset, so no per-lane address arithmetic (a chunk beyond d stays out of range through its per-lane
+  // offset).
+  auto load_piece = [&](const srd_t srd, int t, int i) __attribute__((always_inline)) {
+    const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)t * tile_step);
+    if constexpr (kLandAcc) {
+      // (s_nop 4: with the scalar registers as short as they are in this kernel the compiler keeps uniform
+      // values in vector registers and moves them over right in front of their use; see settle_scalars)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
+                   : "=a"(land[i][0]), "=a"(land[i][1])
+                   : "v"(dma_off[i]), "s"(srd), "s"(soff)
+                   : "memory");
+    } else {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(((uint64_t)(srd[1] & 0xffffu) << 32) | srd[0]), 0, srd[2], 0x00020000);
+      land[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i], soff, 0);
+      land[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i] + 16u, soff, 0);
+    }
+  };
+  const uint32_t lds_lane = (uint32_t)(wave * kPiecesPerWave * 1024 + lane * 16);
+  // `younger`: loads issued after this piece's two
+  auto wait_piece = [&](int i, int younger) __attribute__((always_inline)) {
+    switch (younger) {  // (an immediate operand)
+      case 0: asm volatile("s_waitcnt vmcnt(0)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(6)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
+    }
+  };
+  auto write_piece = [&](bool v_side, int slot, int i) __attribute__((always_inline)) {
+    if constexpr (kLandAcc) wait_piece(i, 2 * (kPiecesPerWave - 1 - i));
+    *FLASH_LDS_CAST(f16x8, (v_side ? v_ring : k_ring) + slot * kTileBytes + i * 1024 + lds_lane) =
+        q_frag_from_f32(land[i][0], land[i][1]);
+  };
   // LDS address of this wave's first piece in slot 0 of the K ring; the ring (K or V), the slot and the
   // piece number add a compile-time constant
   const uint32_t lds_wave_base =
       __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(k_ring + wave * kPiecesPerWave * 1024));
-  auto piece = [&](const srd_t srd, bool v_side, int slot, int t, int i) __attribute__((always_inline)) {
-    // whole tiles only (N % 64 == 0): the tile offset can bypass the range check as a scalar offset
-    dma_piece_at(srd, dma_off[i], __builtin_amdgcn_readfirstlane((uint32_t)t * tile_step), lds_wave_base,
-                 (uint32_t)(((v_side ? kRingP : 0) + slot) * kTileBytes + i * 1024));
+  // `soff` = tile number * tile_step, wave-uniform: whole tiles only (N % 64 == 0), so the tile offset can
+  // bypass the range check as a scalar offset
+  auto piece = [&](const srd_t srd, bool v_side, int slot, uint32_t soff, int i) __attribute__((always_inline)) {
+    dma_piece_at(srd, dma_off[i], soff, lds_wave_base, (uint32_t)(((v_side ? kRingP : 0) + slot) * kTileBytes + i * 1024));
   };
   auto staged_barrier = [&]() __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
   auto head_of = [&](uint32_t it) __attribute__((always_inline)) { return it / (uint32_t)p.nqt; };
-  constexpr bool QF32 = kQFromF32<TO>;
+  // (with fp32 K and V the eight-wave layout reads Q as fp32 too: all of a wave's Q lands in the score,
+  // probability and fragment registers that are free between two items)
+  constexpr bool QF32 = kQFromF32<TO> || KV32;
   constexpr uint32_t kQElem = QF32 ? 4u : 2u;
   // Cache policy of the output stores.  O is written once and never read back: in the long-sequence
   // d = 128 kernel the stores go through to memory (sc0 sc1 nt), so that O lines neither sit dirty in the
@@ -1054,7 +1178,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   f16x8 qf[kQ16][kKS];
   auto fetch_q = [&](uint32_t it) __attribute__((always_inline)) {
     const uint32_t hd = head_of(it), qt = it - hd * (uint32_t)p.nqt;
-    const srd_t q_srd = make_srd((const f16*)p.q + (size_t)hd * head_elems, head_bytes);
+    srd_t q_srd = make_srd((const f16*)p.q + (size_t)hd * head_elems, head_bytes);
+    settle_scalars(q_srd);
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
@@ -1070,7 +1195,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   // in phases of at most 64 landing registers (the epilogue needs room of its own): phase ph covers
   // query blocks [ph * kQPerPhase, (ph + 1) * kQPerPhase) and is converted behind the output stores of
   // the same query blocks.
-  constexpr int kQPhases = (QF32 && kQ16 * kKS > 8) ? 2 : 1;
+  // (With fp32 K and V as well, the first phase is fetched a whole step earlier, at the item's last Q K^T
+  // product, into the registers of the score tile, K fragments and references that step no longer needs.)
+  constexpr int kQPhases = (QF32 && (kQ16 * kKS > 8 || (kWaves == 8 && D == 128))) ? 2 : 1;
+  // the early scheme described above (four-wave layout with fp32 K and V)
+  constexpr bool kQEarly = KV32 && kQ16 == 4;
   constexpr int kQPerPhase = kQ16 / kQPhases;
   u32x4 q_land[QF32 ? kQPerPhase : 1][QF32 ? kKS : 1][2];
   auto fetch_q32 = [&](uint32_t it, int ph) __attribute__((always_inline)) {
@@ -1082,9 +1211,19 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       for (int q = 0; q < kQPerPhase; ++q) {
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
-          const uint32_t off = q_off[ph * kQPerPhase + q][ks] + qt * q_tile_bytes;
-          q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
-          q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off + 16u, 0, 0);
+          if constexpr (KV32) {
+            // per-lane offsets of query block 0 only (four registers instead of sixteen): the block and
+            // the tile are a wave-uniform offset, which the range check does not see (whole tiles: every
+            // row exists; a chunk beyond d stays out of range through its per-lane part)
+            const uint32_t soff = __builtin_amdgcn_readfirstlane(
+                qt * q_tile_bytes + (uint32_t)((ph * kQPerPhase + q) * 16) * (uint32_t)d * kQElem);
+            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[0][ks], soff, 0);
+            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[0][ks] + 16u, soff, 0);
+          } else {
+            const uint32_t off = q_off[ph * kQPerPhase + q][ks] + qt * q_tile_bytes;
+            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
+            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off + 16u, 0, 0);
+          }
         }
       }
     }
@@ -1104,21 +1243,60 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   };
 
   // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
-  srd_t k_srd = make_srd((const f16*)p.k + (size_t)head_of(item) * head_elems, head_bytes);
-  srd_t v_srd = make_srd((const f16*)p.v + (size_t)head_of(item) * head_elems, head_bytes);
+  srd_t k_srd = kv_srd(p.k, head_of(item)), v_srd = kv_srd(p.v, head_of(item));
+  settle_scalars(k_srd, v_srd);
   if constexpr (QF32) {
     fetch_q32(item, 0);
   } else {
     fetch_q(item);
   }
+  if constexpr (KV32) {
+    // K tile 0 and V tile 0 in flight together with the first half of Q, K tile 1 with the second half
+    // (everything at once does not fit the register file next to the loop's long-lived values)
+    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.k + (size_t)head_of(item) * head_elems * kKVElem), 0, head_bytes * (kKVElem / 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.v + (size_t)head_of(item) * head_elems * kKVElem), 0, head_bytes * (kKVElem / 2u), 0x00020000);
+    u32x4 cold[2][kPiecesPerWave][2];
+    auto cold_load = [&](int w, const __amdgpu_buffer_rsrc_t rs, uint32_t toff) __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 0, 0, i);
+      for (int i = 0; i < kPiecesPerWave; ++i) {
+        cold[w][i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i] + toff, 0, 0);
+        cold[w][i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i] + toff + 16u, 0, 0);
+      }
+    };
+    auto cold_write = [&](int w, lds_char* dst) __attribute__((always_inline)) {
 #pragma unroll
-  for (int i = 0; i < kPiecesPerWave; ++i) piece(v_srd, true, 0, 0, i);
+      for (int i = 0; i < kPiecesPerWave; ++i)
+        *FLASH_LDS_CAST(f16x8, dst + i * 1024 + lds_lane) = q_frag_from_f32(cold[w][i][0], cold[w][i][1]);
+    };
+    cold_load(0, k_rs, 0u);
+    cold_load(1, v_rs, 0u);
+    __builtin_amdgcn_sched_barrier(0);
+    convert_q32(0);
+    if constexpr (kQPhases > 1) fetch_q32(item, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    cold_write(0, k_ring);
+    cold_write(1, v_ring);
+    __builtin_amdgcn_sched_barrier(0);
+    cold_load(0, k_rs, tile_step);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kQPhases > 1) convert_q32(1);
+    cold_write(0, k_ring + kTileBytes);
+    __builtin_amdgcn_sched_barrier(0);
+  } else {
 #pragma unroll
-  for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 1, 1, i);
+    for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 0, 0u, i);
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i) piece(v_srd, true, 0, 0u, i);
+    uint32_t one_tile = __builtin_amdgcn_readfirstlane(tile_step);
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i) piece(k_srd, false, 1, one_tile, i);
+  }
   const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
-  if constexpr (QF32) {
+  if constexpr (KV32) {
+    // (converted above, between the cold K/V loads)
+  } else if constexpr (QF32) {
     convert_q32(0);
     if constexpr (kQPhases > 1) {
       fetch_q32(item, 1);
@@ -1211,41 +1389,70 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       int k_tile = t + 2, v_tile = t + 1;
       if constexpr (CROSS) {
         if (!k_cur_item) {
-          ks_srd = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
+          ks_srd = kv_srd(p.k, next_head);
           k_tile = t + 2 - nt;
         }
         if (!v_cur_item) {
-          vs_srd = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);
+          vs_srd = kv_srd(p.v, next_head);
           v_tile = t + 1 - nt;
         }
       }
       const bool k_go = k_cur_item || has_next, v_go = v_cur_item || has_next;
-      auto no_hook = [](int) __attribute__((always_inline)) {};
+      uint32_t k_soff = __builtin_amdgcn_readfirstlane((uint32_t)k_tile * tile_step);
+      uint32_t v_soff = __builtin_amdgcn_readfirstlane((uint32_t)v_tile * tile_step);
+      // the descriptors and tile offsets of another head are computed here, not in front of their first use
+      // (the loads of fp32 tiles carry their own wait states)
+      if constexpr (CROSS && !KV32) settle_scalars(ks_srd, vs_srd, k_soff, v_soff);
       auto dma_hook = [&](int n) __attribute__((always_inline)) {
         constexpr int kSpacing = (2 * kKS + kDv16) * kQ16 / (2 * kPiecesPerWave);
         if (n % kSpacing == 1) {
           const int i = n / kSpacing;
           if (i < kPiecesPerWave) {
-            if (!CROSS || k_go) piece(ks_srd, false, S2, k_tile, i);
+            if (!CROSS || k_go) piece(ks_srd, false, S2, k_soff, i);
           } else if (i < 2 * kPiecesPerWave) {
-            if (!CROSS || v_go) piece(vs_srd, true, S1, v_tile, i - kPiecesPerWave);
+            if (!CROSS || v_go) piece(vs_srd, true, S1, v_soff, i - kPiecesPerWave);
           }
         }
+      };
+      // fp32 K/V: one tile per step, the K tile in the first and the V tile in the second; loads in the
+      // step's first slots, conversion and LDS writes in its last ones
+      auto vec_hook = [&](int n, bool v_side) __attribute__((always_inline)) {
+        constexpr int kSlots = (2 * kKS + kDv16) * kQ16;
+        constexpr int kFirstWrite = kSlots - 2 * kPiecesPerWave - 2;
+        const bool go = !CROSS || (v_side ? v_go : k_go);
+        if (n >= 1 && n < 1 + 2 * kPiecesPerWave && (n - 1) % 2 == 0) {
+          if (go) load_piece(v_side ? vs_srd : ks_srd, v_side ? v_tile : k_tile, (n - 1) / 2);
+        }
+        if (n >= kFirstWrite && n < kFirstWrite + 2 * kPiecesPerWave && (n - kFirstWrite) % 2 == 0) {
+          if (go) write_piece(v_side, v_side ? S1 : S2, (n - kFirstWrite) / 2);
+        }
+      };
+      auto hook1 = [&](int n) __attribute__((always_inline)) {
+        if constexpr (KV32) {
+          vec_hook(n, false);
+        } else {
+          dma_hook(n);
+        }
+      };
+      auto hook2 = [&](int n) __attribute__((always_inline)) {
+        if constexpr (KV32) vec_hook(n, true);
       };
       constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
       constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
       pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate, EK>(
-          dma_hook, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, mx_all, lsum, sc, pending, vote, 0, N, lane);
+          hook1, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, mx_all, lsum, sc, pending, vote, 0, N, lane);
       step_end<kDv16, true>(o, st, mx_all, lsum, bias, sB, pending, vote, sc, lane);
       if constexpr (LAST) {
         // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
         // loads have the last step, the last P V product and the output stores to land.
-        if constexpr (!QF32) {
+        if constexpr (kQEarly) {
+          if (has_next) fetch_q32(next_item, 0);
+        } else if constexpr (!QF32) {
           if (has_next) fetch_q(next_item);
         }
       }
       pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate, EK>(
-          no_hook, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all, lsum, sc, pending, vote, 0, N, lane);
+          hook2, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all, lsum, sc, pending, vote, 0, N, lane);
       step_end<kDv16, !LAST>(o, st, mx_all, lsum, bias, sA, pending, vote, sc, lane);
       if constexpr (LAST) {
         // wait for this wave's staging pieces, which are older than the Q loads, but not for those
@@ -1292,9 +1499,15 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       drain_o(o);
       drain_lsum<D>(lsum);
     }
+    if constexpr (kQEarly) {
+      if (has_next) {
+        convert_q32(0);
+        if constexpr (kQPhases > 1) fetch_q32(next_item, 1);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
-      if constexpr (QF32) {
+      if constexpr (QF32 && !kQEarly) {
         if (q % kQPerPhase == 0) {
           // (the Q registers have been free since the item's last Q K^T product)
           if (q > 0 && has_next) convert_q32(q / kQPerPhase - 1);
@@ -1320,7 +1533,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 #endif
     if (!has_next) break;
     // the Q loads are older than this item's output stores: wait for everything but those stores
-    if constexpr (QF32) {
+    if constexpr (kQEarly && kQPhases == 1) {
+      // (converted right behind the last P V product)
+    } else if constexpr (QF32) {
       convert_q32(kQPhases - 1);
     } else {
       wait_q<kQ16 * OutStores<TO>::per_block(kDv16)>(qf);
@@ -1332,8 +1547,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     ++n_items;
 #endif
     item = next_item;
-    k_srd = make_srd((const f16*)p.k + (size_t)next_head * head_elems, head_bytes);
-    v_srd = make_srd((const f16*)p.v + (size_t)next_head * head_elems, head_bytes);
+    k_srd = kv_srd(p.k, next_head);
+    v_srd = kv_srd(p.v, next_head);
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }

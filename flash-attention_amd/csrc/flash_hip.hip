@@ -54,6 +54,7 @@ const char* const kNames[FLASH_KT_COUNT] = {
 struct Plan {
   int tile_d;      // 64 or 128
   bool fast;       // fp16 data with 16-byte row chunks: direct-to-LDS staging
+  bool vec;        // fp32 data with 32-byte row chunks: 128-bit loads, converted in registers
   int staging;     // flash_launch_info.staging
   uint32_t lds;
   uint32_t nqt;
@@ -95,7 +96,8 @@ int make_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, bool 
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "grid of %lld workgroups is too large", (long long)(B * H * nqt));
   plan->tile_d = d <= 64 ? 64 : 128;
   plan->fast = fp16_io && (d % 8 == 0);
-  plan->staging = plan->fast ? kStageDma : kStageElem;
+  plan->vec = !fp16_io && (d % 8 == 0);
+  plan->staging = plan->fast ? kStageDma : (plan->vec ? kStageVec : kStageElem);
   plan->lds = plan->tile_d == 64 ? Geom<64>::kLdsBytes : Geom<128>::kLdsBytes;
   plan->nqt = (uint32_t)nqt;
   return FLASH_HIP_OK;
@@ -131,22 +133,55 @@ FwdParams make_params(const void* q, const void* k, const void* v, void* o, int6
   return prm;
 }
 
+// Per-device facts the launchers need on every call, kept process-wide (any thread may warm a device up
+// for any other: a HIP graph captured on one thread after a plain call on another finds every attribute
+// set).  Ordinals beyond the table (partitioned nodes expose up to 64 devices; the table holds that many)
+// are served without the cache.
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_cu_count[kMaxDevices];
+
+int current_device(int* dev) {
+  hipError_t e = hipGetDevice(dev);
+  if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "hipGetDevice failed: %s", hipGetErrorString(e));
+  return FLASH_HIP_OK;
+}
+
+// Workgroups of the persistent kernel on device `dev`: one per CU (the kernel needs a CU's whole
+// register file and most of its LDS), never more than there are items.
+uint32_t persistent_grid(uint32_t items, int dev) {
+  int n = (dev >= 0 && dev < kMaxDevices) ? g_cu_count[dev].load(std::memory_order_relaxed) : 0;
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < kMaxDevices) g_cu_count[dev].store(n, std::memory_order_relaxed);
+  }
+  const uint32_t g = (uint32_t)n & ~7u;  // a multiple of the 8 XCDs
+  return items < g ? items : (g ? g : 8u);
+}
+
+// One bit per device ordinal: the kernel's dynamic-LDS attribute has been set there.
+struct AttrDone {
+  std::atomic<uint64_t> mask{0};
+};
+
+// grid == 0: one workgroup per item; kPersistentGrid: one per CU of the current device.
+constexpr uint32_t kPersistentGrid = 0xffffffffu;
+
 template <typename Kernel>
-int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, bool (&attr_done)[16],
+int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t stream, AttrDone& attr_done,
                   uint32_t grid = 0, uint32_t threads = kThreads) {
+  int dev = 0;
+  int rc = current_device(&dev);
+  if (rc != FLASH_HIP_OK) return rc;
   if (grid == 0) grid = prm.total_wg;
+  if (grid == kPersistentGrid) grid = persistent_grid(prm.total_wg, dev);
   // Above the 64 KiB default a kernel must opt in to its dynamic LDS size (the reference does the
   // same above 48 KiB, launch.cu:134-148).
-  int dev = 0;
-  hipError_t de = hipGetDevice(&dev);
-  if (de != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "hipGetDevice failed: %s", hipGetErrorString(de));
-  // the per-device cache covers ordinals 0..15; beyond that (partitioned nodes expose up to 64
-  // devices) the attribute is simply set on every call
-  if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+  const bool cached = dev >= 0 && dev < kMaxDevices;
+  if (!cached || !((attr_done.mask.load(std::memory_order_acquire) >> dev) & 1u)) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
       return fail(FLASH_HIP_ERR_LDS, "Failed to set dynamic shared memory size %u: %s", lds, hipGetErrorString(e));
-    if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    if (cached) attr_done.mask.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
 #if defined(FLASH_PHASE_STAMPS)
   // diagnostic build: collect and print the per-wave phase stamps of this launch (synchronises)
@@ -189,43 +224,73 @@ int launch_kernel(Kernel kern, const FwdParams& prm, uint32_t lds, hipStream_t s
 
 template <int D, typename T, bool FAST>
 int launch(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
-  static thread_local bool attr_done[16] = {};
+  static AttrDone attr_done;
   return launch_kernel(attn_fwd_kernel<D, T, FAST>, prm, lds, stream, attr_done);
 }
 
 // fp16 rows of a multiple of 8 elements: the 16x16x32-MFMA kernel; TO = element type of O
 template <int D, typename TO>
 int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
-  static thread_local bool attr_done[16] = {};
+  static AttrDone attr_done;
   return launch_kernel(m16::attn_fwd_kernel_m16<D, TO>, prm, lds, stream, attr_done);
 }
 
-// FLASH_HIP_PERSISTENT=0 in the environment routes whole-tile shapes to the one-item-per-workgroup
-// kernel as well (for A/B measurements; read on every call so that a harness can flip it).
-static bool use_persistent() {
-  const char* e = getenv("FLASH_HIP_PERSISTENT");
-  return !(e && e[0] == '0');
-}
+// Longest sequence on which fp32 callers that bring a workspace still take the register-staged kernel.
+// The conversion pass costs one more trip of K and V through HBM plus a launch that cannot overlap the
+// attention kernel; converting in the kernel costs every workgroup that reads a K/V tile 32 conversions
+// and twice the L2 -> LDS bytes.  Few readers per tile (N / 256 of them) favour the latter.  Measured
+// (tests/native/selftest benchf32, TFLOP/s in-kernel / pass): (4,96,N,128) 478 / 385 at N = 512, 680 / 617 at
+// 1024, 860 / 850 at 2048, 965 / 1020 at 4096; (16,32,N,64) 483 / 349 at 512, 518 / 580 at 1024 (there the
+// pass is followed by the 128-rows-per-wave layout, which the fp32 kernels do not have).
+constexpr int64_t kVecDefaultMaxN128 = 2048;
+constexpr int64_t kVecDefaultMaxN64 = 768;
 
-// Longest sequence routed to the persistent kernel (FLASH_HIP_PERSISTENT_MAX_N overrides, for A/B runs).
-static int64_t persistent_max_n() {
-  const char* e = getenv("FLASH_HIP_PERSISTENT_MAX_N");
-  return e ? atoll(e) : (int64_t)1 << 40;
+// Routing switches for A/B measurements, from the environment:
+//   FLASH_HIP_PERSISTENT=0         whole-tile shapes go to the one-item-per-workgroup kernel as well
+//   FLASH_HIP_PERSISTENT_MAX_N=<n> longest sequence routed to the persistent kernel
+//   FLASH_HIP_WIDE_MAX_N=<n>       longest sequence that gets the eight-wave layout (0 = never)
+//   FLASH_HIP_TALL=0               keep head dims up to 64 on 256-row query tiles
+//   FLASH_HIP_VEC_MAX_N=<n>        longest sequence on which fp32 callers with a workspace still take the
+//                                  register-staged kernel instead of the conversion pass (0 = never)
+// They are read once per process, on the first call that routes anything, and again only when
+// flash_hip_reload_switches() is called: the hot path does no environment lookups, and a warmed-up HIP graph
+// capture stays on the kernels it was warmed up with.
+struct Switches {
+  bool persistent;
+  int64_t persistent_max_n;
+  int64_t wide_max_n;
+  bool tall;
+  int64_t vec_max_n;  // < 0: the per-head-dim defaults
+};
+Switches read_switches() {
+  auto flag = [](const char* name) {
+    const char* e = getenv(name);
+    return !(e && e[0] == '0');
+  };
+  auto num = [](const char* name, int64_t dflt) {
+    const char* e = getenv(name);
+    return e ? (int64_t)atoll(e) : dflt;
+  };
+  Switches s;
+  s.persistent = flag("FLASH_HIP_PERSISTENT");
+  s.persistent_max_n = num("FLASH_HIP_PERSISTENT_MAX_N", (int64_t)1 << 40);
+  s.wide_max_n = num("FLASH_HIP_WIDE_MAX_N", (int64_t)1 << 40);
+  s.tall = flag("FLASH_HIP_TALL");
+  s.vec_max_n = num("FLASH_HIP_VEC_MAX_N", -1);
+  return s;
 }
-
-// Workgroups of the persistent kernel: one per CU (the kernel needs a CU's whole register file and
-// most of its LDS), never more than there are items.
-static uint32_t persistent_grid(uint32_t items) {
-  static thread_local int cus[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-  if (cus[dev] == 0) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cus[dev] = n;
-  }
-  const uint32_t g = (uint32_t)cus[dev] & ~7u;  // a multiple of the 8 XCDs
-  return items < g ? items : (g ? g : 8u);
+// The current set: published through one pointer, so a reload is safe against calls in flight on other
+// threads (they route by the old set or the new one, never by a mixture).  Old sets are never freed.
+std::atomic<const Switches*> g_switches{nullptr};
+const Switches* publish_switches() {
+  const Switches* fresh = new Switches(read_switches());
+  g_switches.store(fresh, std::memory_order_release);
+  return fresh;
+}
+Switches switches() {
+  const Switches* s = g_switches.load(std::memory_order_acquire);
+  if (!s) s = publish_switches();  // racing first calls read the same environment
+  return *s;
 }
 
 // Whole-tile d = 128 shapes run the persistent kernel in the eight-wave layout (two waves per SIMD, 32
@@ -234,13 +299,29 @@ static uint32_t persistent_grid(uint32_t items) {
 // wave alone is issue-bound.  On long sequences the saved cycles (10 %) come back as a lower clock on
 // boxes that sit at the power cap (same time) and as time on the others: measured +0.2 %, +0.9 %, +1.3 %,
 // +4.2 % at (8,96,4096,128) on four boxes, +4 % at N = 8192 and 16384 on the slowest, never slower than
-// within noise.  d = 64 gains nothing from it at any length.  FLASH_HIP_WIDE_MAX_N=<n> limits the layout
-// to sequences up to n (0 = never; A/B measurements; read on every call).
-static int64_t wide_max_n() {
-  const char* e = getenv("FLASH_HIP_WIDE_MAX_N");
-  return e ? atoll(e) : (int64_t)1 << 40;
+// within noise.  d = 64 gains nothing from it at any length.
+bool use_wide(const Switches& sw, int tile_d, int64_t N) { return tile_d == 128 && N <= sw.wide_max_n; }
+
+// d = 64 leaves room for 128 query rows per wave (O^T and Q take the registers they take at d = 128 with
+// 64 rows): a 512-row query tile per workgroup, i.e. half the K/V staging traffic and half the LDS
+// fragment reads per FLOP.  Whole 512-row tiles only.
+bool use_tall(const Switches& sw, int tile_d, int64_t N) { return tile_d == 64 && N % m16x::kBr == 0 && sw.tall; }
+
+// fp32 Q, K, V, O with rows of a multiple of 8 elements: the same kernels with register staging (128-bit
+// fp32 loads, rounded to fp16 on their way into LDS), four waves x 64 query rows.  Whole query tiles run the
+// persistent kernel, ragged N one work item per workgroup.
+template <int D>
+int launch_m16_vec(const FwdParams& prm, uint32_t lds, bool persistent, hipStream_t stream) {
+  if (persistent) {
+    // (four waves x 64 query rows also at d = 128: the eight-wave layout has no registers left to land fp32
+    // tiles in and measured 10-20 % slower here)
+    static AttrDone attr_done_p;
+    return launch_kernel(m16::attn_fwd_kernel_m16p<D, float, true>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream,
+                         attr_done_p, kPersistentGrid, (uint32_t)m16::kThreads);
+  }
+  static AttrDone attr_done;
+  return launch_kernel(m16::attn_fwd_kernel_m16<D, float, true>, prm, lds, stream, attr_done);
 }
-static bool use_wide(int tile_d, int64_t N) { return tile_d == 128 && N <= wide_max_n(); }
 
 // the eight-wave layout's name for an output type (the bfloat16 tag is declared per layout)
 template <typename TO>
@@ -252,14 +333,6 @@ struct WideOut<m16::bf16_out> {
   using type = m16w::bf16_out;
 };
 
-// d = 64 leaves room for 128 query rows per wave (O^T and Q take the registers they take at d = 128 with
-// 64 rows): a 512-row query tile per workgroup, i.e. half the K/V staging traffic and half the LDS
-// fragment reads per FLOP.  Whole 512-row tiles only.  FLASH_HIP_TALL=0 turns it off (A/B measurements).
-static bool use_tall(int tile_d, int64_t N) {
-  if (tile_d != 64 || N % m16x::kBr != 0) return false;
-  const char* e = getenv("FLASH_HIP_TALL");
-  return !(e && e[0] == '0');
-}
 template <typename TO>
 struct TallOut {
   using type = TO;
@@ -272,22 +345,21 @@ struct TallOut<m16::bf16_out> {
 // whole query tiles (N % 256 == 0): persistent workgroups with uninterrupted K/V staging
 template <int D, typename TO>
 int launch_m16p(const FwdParams& prm, hipStream_t stream) {
-  static thread_local bool attr_done[16] = {};
+  static AttrDone attr_done;
   return launch_kernel(m16::attn_fwd_kernel_m16p<D, TO>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream, attr_done,
-                       persistent_grid(prm.total_wg), (uint32_t)m16::kThreads);
+                       kPersistentGrid, (uint32_t)m16::kThreads);
 }
 template <typename TO>
 int launch_m16p_wide(const FwdParams& prm, hipStream_t stream) {
-  static thread_local bool attr_done[16] = {};
+  static AttrDone attr_done;
   static_assert(m16w::CfgP<128>::kLdsBytes == m16::CfgP<128>::kLdsBytes, "both layouts use the same LDS rings");
   return launch_kernel(m16w::attn_fwd_kernel_m16p<128, typename WideOut<TO>::type>, prm,
-                       (uint32_t)m16w::CfgP<128>::kLdsBytes, stream, attr_done, persistent_grid(prm.total_wg),
+                       (uint32_t)m16w::CfgP<128>::kLdsBytes, stream, attr_done, kPersistentGrid,
                        (uint32_t)m16w::kThreads);
 }
 
-// Which of the 16x16x32 kernels a whole-row-chunk shape goes to.  Decided once per call (the switches are
-// environment variables that a harness may flip between calls) and handed down, so that the conversion
-// pass and the kernel launch of one call agree.
+// Which of the 16x16x32 kernels a whole-row-chunk shape goes to.  Decided once per call and handed down,
+// so that the conversion pass and the kernel launch of one call agree.
 enum Route : int {
   kRouteItem = 0,     // one work item per workgroup (ragged N)
   kRoutePersistent,   // persistent workgroups, four waves x 64 query rows
@@ -297,10 +369,17 @@ enum Route : int {
 // fp32 callers (the fp16 kernels with fp32 output): beyond N = 512 they stay on the four-wave layout, whose
 // kernels read Q as fp32 themselves, which is worth more than the eight-wave layout (measured at
 // (4,96,N,128): N = 1024 +5..12 %, N = 512 -1 %)
-static Route pick_route(const Plan& plan, int64_t N, bool fp32_out) {
-  if (!(N % kBr == 0 && N <= persistent_max_n() && use_persistent())) return kRouteItem;
-  if (use_wide(plan.tile_d, N)) return (fp32_out && N > 512) ? kRoutePersistent : kRouteWide;
-  return use_tall(plan.tile_d, N) ? kRouteTall : kRoutePersistent;
+Route pick_route(const Plan& plan, int64_t N, bool fp32_out) {
+  const Switches sw = switches();
+  if (!(N % kBr == 0 && N <= sw.persistent_max_n && sw.persistent)) return kRouteItem;
+  if (use_wide(sw, plan.tile_d, N)) return (fp32_out && N > 512) ? kRoutePersistent : kRouteWide;
+  return use_tall(sw, plan.tile_d, N) ? kRouteTall : kRoutePersistent;
+}
+
+// fp32 tensors converted inside the attention kernel: persistent workgroups for whole query tiles
+bool vec_persistent(int64_t N) {
+  const Switches sw = switches();
+  return N % kBr == 0 && N <= sw.persistent_max_n && sw.persistent;
 }
 
 // fp16 Q, K, V with 16-byte row chunks, O as fp16 or fp32
@@ -315,9 +394,9 @@ int launch_fast(const FwdParams& prm, const Plan& plan, Route route, hipStream_t
       FwdParams tall = prm;  // the same heads cut into 512-row query tiles
       tall.nqt = (int)(prm.N / m16x::kBr);
       tall.total_wg = prm.total_wg / (uint32_t)prm.nqt * (uint32_t)tall.nqt;
-      static thread_local bool attr_done[16] = {};
+      static AttrDone attr_done;
       return launch_kernel(m16x::attn_fwd_kernel_m16p<64, typename TallOut<TO>::type>, tall,
-                           (uint32_t)m16x::CfgP<64>::kLdsBytes, stream, attr_done, persistent_grid(tall.total_wg),
+                           (uint32_t)m16x::CfgP<64>::kLdsBytes, stream, attr_done, kPersistentGrid,
                            (uint32_t)m16x::kThreads);
     }
     case kRoutePersistent:
@@ -359,8 +438,26 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
 #endif
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    if (plan.vec && aligned16(q, k, v, o)) {
+      const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, false);
+      const bool persistent = vec_persistent(N);
+      return plan.tile_d == 64 ? launch_m16_vec<64>(prm, plan.lds, persistent, stream)
+                               : launch_m16_vec<128>(prm, plan.lds, persistent, stream);
+    }
+  }
   const FwdParams prm = make_params(q, k, v, o, B, H, N, d, softmax_scale, plan, true);
   return plan.tile_d == 64 ? launch<64, T, false>(prm, plan.lds, stream) : launch<128, T, false>(prm, plan.lds, stream);
+}
+
+// fp16 copies the conversion pass of flash_fwd_f32_ws writes for this shape: none when the call converts
+// inside the attention kernel (rows without 16-byte chunks, sequences up to the register-staging limit),
+// K and V, or Q as well for the wave layouts that cannot read it as fp32.
+int cast_copies(const Plan& plan, int64_t N) {
+  const int64_t vec_max_n = switches().vec_max_n;
+  if (!plan.fast || N <= (vec_max_n >= 0 ? vec_max_n : (plan.tile_d == 64 ? kVecDefaultMaxN64 : kVecDefaultMaxN128))) return 0;
+  const Route route = pick_route(plan, N, true);
+  return (route == kRouteTall || route == kRouteWide) ? 3 : 2;
 }
 
 // fp32 tensors through scratch memory: one conversion pass into three fp16 copies, then the fp16
@@ -372,24 +469,24 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   Plan plan;
   int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
   if (rc != FLASH_HIP_OK) return rc;
-  // rows without 16-byte chunks, no workspace, or tensors that do not start on a 16-byte boundary:
-  // convert while staging
-  if (!plan.fast || !workspace || !aligned16(q, k, v, o))
+  // rows without 16-byte chunks, a sequence short enough for the register-staged kernel, no workspace, or
+  // tensors that do not start on a 16-byte boundary: convert while staging
+  const int n_cast = cast_copies(plan, N);
+  if (n_cast == 0 || !workspace || !aligned16(q, k, v, o))
     return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
   if ((rc = check_scale(softmax_scale)) != FLASH_HIP_OK) return rc;
   if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
   const int64_t each = ws_tensor_bytes(B, H, N, d);
-  if (workspace_bytes < kCastTensors * each)
+  if (workspace_bytes < n_cast * each)
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace of %lld bytes is too small: %lld needed",
-                (long long)workspace_bytes, (long long)(kCastTensors * each));
+                (long long)workspace_bytes, (long long)(n_cast * each));
   if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
   hipStream_t stream = (hipStream_t)hip_stream;
   // K and V, which every query tile of a head re-reads; Q is read by one workgroup per row and the
   // attention kernels take it from the caller's fp32 tensor (m16::kQFromF32), except in the
   // 128-rows-per-wave and eight-wave layouts.  The workspace keeps its three-slot layout (K, V, then Q if converted).
   const Route route = pick_route(plan, N, true);
-  const bool cast_q = route == kRouteTall || route == kRouteWide;
-  const int n_cast = cast_q ? 3 : 2;
+  const bool cast_q = n_cast == 3;
   CastParams cp{};
   const void* src[kCastTensors] = {k, v, q};
   for (int i = 0; i < n_cast; ++i) {
@@ -412,7 +509,6 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
 // its own copy at its own address; the array's name is only a host-side handle for
 // hipGetSymbolAddress and is never used as a pointer.  Resolved once per device, with that device
 // current, on the first call that needs it there.
-constexpr int kMaxDevices = 64;
 std::atomic<void*> g_scratch_ptr[kMaxDevices];
 
 int static_scratch_ptr(void** out) {
@@ -465,7 +561,7 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type) {
   Plan plan;
   if (make_plan(B, H, N, d, kernel_type, true, &plan) != FLASH_HIP_OK) return -1;
-  return plan.fast ? kCastTensors * ws_tensor_bytes(B, H, N, d) : 0;
+  return (int64_t)cast_copies(plan, N) * ws_tensor_bytes(B, H, N, d);
 }
 
 int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o, int64_t B, int64_t H, int64_t N, int64_t d,
@@ -478,12 +574,14 @@ int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o, i
   Plan plan;
   int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
   if (rc != FLASH_HIP_OK) return rc;
-  const int64_t need = plan.fast ? kCastTensors * ws_tensor_bytes(B, H, N, d) : 0;
+  // what this call will really put into the buffer: nothing when it converts inside the attention kernel
+  // (tensors off a 16-byte boundary included), else the two or three copies of the conversion pass
+  const int64_t need = aligned16(q, k, v, o) ? (int64_t)cast_copies(plan, N) * ws_tensor_bytes(B, H, N, d) : 0;
   if (need > kStaticScratchBytes)
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT,
-                "flash_fwd_f32_static: this shape needs %lld bytes of scratch, the built-in buffer holds %lld "
-                "(B*H*N*d <= %lld elements); use flash_fwd_f32_ws with caller memory",
-                (long long)need, (long long)kStaticScratchBytes, (long long)(kStaticScratchBytes / kCastTensors / 2));
+                "flash_fwd_f32_static: this shape needs %lld bytes of scratch, the built-in buffer holds %lld; "
+                "use flash_fwd_f32_ws with caller memory",
+                (long long)need, (long long)kStaticScratchBytes);
   void* ws = nullptr;
   if (need > 0) {
     rc = static_scratch_ptr(&ws);
@@ -502,8 +600,16 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   if (entry < FLASH_ENTRY_F16 || entry > FLASH_ENTRY_F32_WS)
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "unknown entry point selector %d", entry);
   Plan plan;
-  // flash_fwd_f32 (no workspace) stages fp32 elements through registers whatever the head dim
-  int rc = make_plan(B, H, N, d, kernel_type, entry != FLASH_ENTRY_F32, &plan);
+  // fp32 callers whose call converts inside the attention kernel (no workspace, or a sequence up to the
+  // register-staging limit) are described as flash_fwd_f32 launches them
+  bool f32_in_kernel = entry == FLASH_ENTRY_F32;
+  if (entry == FLASH_ENTRY_F32_WS) {
+    Plan probe;
+    int prc = make_plan(B, H, N, d, kernel_type, true, &probe);
+    if (prc != FLASH_HIP_OK) return prc;
+    f32_in_kernel = cast_copies(probe, N) == 0;
+  }
+  int rc = make_plan(B, H, N, d, kernel_type, !f32_in_kernel, &plan);
   if (rc != FLASH_HIP_OK) return rc;
   if (entry == FLASH_ENTRY_BF16 && !plan.fast)
     return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
@@ -512,7 +618,8 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->tile_q = kBr;  // 512 for the 128-rows-per-wave layout, set below
   out->tile_d = (uint32_t)plan.tile_d;
   // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
-  const Route route = plan.fast ? pick_route(plan, N, entry == FLASH_ENTRY_F32_WS) : kRouteItem;
+  const Route route = plan.fast ? pick_route(plan, N, entry == FLASH_ENTRY_F32_WS)
+                                : ((plan.vec && vec_persistent(N)) ? kRoutePersistent : kRouteItem);
   const bool persistent = route != kRouteItem;
   out->lds_bytes = !persistent ? plan.lds
                                : (uint32_t)(plan.tile_d == 64 ? m16::CfgP<64>::kLdsBytes : m16::CfgP<128>::kLdsBytes);
@@ -538,6 +645,11 @@ const char* flash_kernel_type_name(int kernel_type) {
 
 const char* flash_hip_last_error(void) { return g_err; }
 
-int flash_hip_version(void) { return 200; }
+int flash_hip_version(void) { return 300; }
+
+int flash_hip_reload_switches(void) {
+  publish_switches();
+  return FLASH_HIP_OK;
+}
 
 }  // extern "C"

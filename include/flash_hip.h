@@ -10,10 +10,10 @@
  * Conventions
  *   - All tensors are contiguous [B, H, N, d] (reference flash/kernel_mma_qreg.cuh:30-34:
  *     qkv_offset = (b*H + h)*N*d); K and V have the shape of Q; O has the shape of Q.
- *   - Tensor pointers need only the alignment of their element type.  The fast kernels (fp16 and
- *     bfloat16 with d % 8 == 0, flash_fwd_f32_ws) move 16 bytes per lane and are used when q, k, v and o
- *     all start on a 16-byte boundary (any whole allocation does); otherwise fp16 and fp32 tensors take
- *     the slower element-staging kernel, bfloat16 tensors are rejected (INVALID_ARGUMENT).
+ *   - Tensor pointers need only the alignment of their element type.  The fast kernels (any of the three
+ *     tensor types with d % 8 == 0) move 16 bytes per lane and are used when q, k, v and o all start on a
+ *     16-byte boundary (any whole allocation does); otherwise fp16 and fp32 tensors take the slower
+ *     element-staging kernel, bfloat16 tensors are rejected (INVALID_ARGUMENT).
  *   - Device = the calling thread's current HIP device.  `hip_stream` is a hipStream_t (NULL = the
  *     default stream).  Calls enqueue work and return; they never synchronise, allocate or free.
  *   - Return value: FLASH_HIP_OK (0) or a negative flash_hip_status.  The text of the last error of
@@ -70,8 +70,10 @@ typedef struct flash_launch_info {
   uint32_t grid_y;       /* H                                        (gridDim().y)  */
   uint32_t grid_z;       /* ceil(N / Br): grid = the work items; when N % Br == 0 a persistent kernel
                             walks them with one workgroup per CU      (gridDim().z)  */
-  uint32_t staging;      /* 0 = register-staged element loads, 1 = register-staged 128-bit loads,
-                            2 = direct global->LDS loads (buffer_load ... lds) */
+  uint32_t staging;      /* how K/V tiles reach LDS: 0 = element loads through registers (any head dim, any
+                            alignment), 1 = 128-bit fp32 loads through registers, rounded to fp16 on the way
+                            (fp32 tensors, d % 8 == 0), 2 = direct global->LDS loads (buffer_load ... lds;
+                            fp16 / bfloat16 tensors, and fp32 tensors behind the conversion pass) */
   uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */
   uint32_t persistent;   /* 1: the work items (grid_x * grid_y * grid_z of them) are walked by a persistent
                             kernel launched as a 1-D grid of min(items, compute units rounded down to a
@@ -82,9 +84,11 @@ typedef struct flash_launch_info {
 typedef enum flash_hip_entry {
   FLASH_ENTRY_F16 = 0,    /* flash_fwd_f16 */
   FLASH_ENTRY_BF16 = 1,   /* flash_fwd_bf16 */
-  FLASH_ENTRY_F32 = 2,    /* flash_fwd_f32, and flash_fwd_f32_ws without a usable workspace */
-  FLASH_ENTRY_F32_WS = 3  /* flash_fwd_f32_ws with a workspace, flash_fwd_f32_static: the fp16 kernels with fp32
-                             output; the eight-wave layout only up to N = 512 */
+  FLASH_ENTRY_F32 = 2,    /* flash_fwd_f32, and flash_fwd_f32_ws without a usable workspace: conversion inside the
+                             attention kernel, four waves x 64 query rows */
+  FLASH_ENTRY_F32_WS = 3  /* flash_fwd_f32_ws with a workspace, flash_fwd_f32_static: as FLASH_ENTRY_F32 for
+                             sequences up to 2048 (768 for head dims up to 64), beyond that the conversion pass
+                             and the fp16 kernels with fp32 output */
 } flash_hip_entry;
 
 /*
@@ -109,7 +113,7 @@ int flash_fwd_f16(const void* q, const void* k, const void* v, void* o,
  * storage type of the models this shape comes from.  d must be a multiple of 8 (-> UNSUPPORTED_DIM
  * otherwise); other errors as flash_fwd_f16.  P is rounded to 8 mantissa bits before the P V product,
  * so the error against an fp32 evaluation on the same inputs is several times that of fp16
- * (measured max-abs 1e-3 ... 7.4e-3 on standard-normal data; tested against 1.6e-2).
+ * (measured max-abs 1e-3 ... 8.4e-3 on standard-normal data; tested against 1.6e-2).
  */
 int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o,
                    int64_t B, int64_t H, int64_t N, int64_t d,
@@ -119,22 +123,26 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o,
  * fp32 attention forward for the reference's fp32 callers (main.cpp:30-32, benchmarks/bench.py:34-36
  * hand fp32 tensors to flash::forward, which reads them with data_ptr<float>(), launch.cu:165-176).
  * Q, K, V are rounded to fp16 (round-to-nearest-even) while they are staged into LDS/registers, the
- * arithmetic is the same fp16-MFMA / fp32-accumulate pipeline, O is written as fp32.
+ * arithmetic is the same fp16-MFMA / fp32-accumulate pipeline, O is written as fp32.  No workspace, one
+ * kernel.  With d % 8 == 0 and 16-byte-aligned tensors the 16x16x32 kernels of flash_fwd_f16 do the
+ * staging with 128-bit loads (whole query tiles on the persistent kernel); otherwise element by element.
  */
 int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
                   int64_t B, int64_t H, int64_t N, int64_t d,
                   float softmax_scale, int kernel_type, void* hip_stream);
 
 /*
- * fp32 attention forward with a caller-provided workspace: the fast path for the same fp32 callers
- * (reference main.cpp:30-32, benchmarks/bench.py:34-36, flash/launch.cu:165-176; the reference
- * itself allocates per-call scratch for its non-register kernels, launch.cu:150-157).
- * When d % 8 == 0 one streaming pass rounds K and V to fp16 (round-to-nearest-even, the rounding
- * flash_fwd_f32 applies) into `workspace`, and the fp16 kernels of flash_fwd_f16 run on those copies,
- * reading Q from the caller's fp32 tensor (rounded the same way on its way into the registers; two of
- * the wave layouts take Q from the pass as well) and writing O as fp32 straight from the accumulators.  Same results as flash_fwd_f32 up to the order of
- * fp32 additions; about three times its throughput at long sequences, because every K/V element is
- * converted once instead of once per workgroup that reads it.
+ * fp32 attention forward with a caller-provided workspace: the fast path for the same fp32 callers at
+ * every sequence length (reference main.cpp:30-32, benchmarks/bench.py:34-36, flash/launch.cu:165-176; the
+ * reference itself allocates per-call scratch for its non-register kernels, launch.cu:150-157).
+ * Converting inside the attention kernel costs every workgroup that reads a K/V tile its conversion, so
+ * beyond a sequence length where a tile has many readers (N > 2048; N > 768 for head dims up to 64) and
+ * when d % 8 == 0, one streaming pass rounds K and V to fp16 (round-to-nearest-even, the rounding
+ * flash_fwd_f32 applies) into `workspace` once, and the fp16 kernels of flash_fwd_f16 run on those copies,
+ * reading Q from the caller's fp32 tensor (rounded the same way on its way into the registers; the
+ * 128-rows-per-wave layout takes Q from the pass as well) and writing O as fp32 straight from the
+ * accumulators.  Same results as flash_fwd_f32 up to the order of fp32 additions.  Shorter sequences are
+ * handled exactly as by flash_fwd_f32 and touch no workspace.
  * `workspace`: device memory, 16-byte aligned, at least flash_fwd_f32_workspace_bytes(...) bytes;
  * its contents are scratch and must not be touched until the work enqueued by this call has finished.
  * A NULL workspace, or a shape for which flash_fwd_f32_workspace_bytes returns 0, makes the call
@@ -153,10 +161,13 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
  * library runs on, held until the process ends.  The call allocates and frees nothing (no hipMalloc,
  * no allocating library routine); it enqueues the same kernels as flash_fwd_f32_ws on `hip_stream`
  * and gives bit-identical results.
- * Limit: shapes whose workspace (flash_fwd_f32_workspace_bytes) exceeds the built-in buffer, i.e.
- * B*H*N*d > 8 Mi elements, are rejected with INVALID_ARGUMENT and a text naming both sizes; use
- * flash_fwd_f32_ws for those.  Shapes that need no workspace (d % 8 != 0, tensors off a 16-byte
- * boundary) behave like flash_fwd_f32.
+ * Limit: shapes whose workspace (flash_fwd_f32_workspace_bytes) exceeds the built-in buffer are rejected
+ * with INVALID_ARGUMENT and a text naming both sizes; use flash_fwd_f32_ws for those.  The workspace holds
+ * the fp16 copies of K and V (B*H*N*d <= 12 Mi elements fit), and of Q as well where the pass converts it
+ * (head dims up to 64 with N % 512 == 0: 8 Mi elements).  Calls that need no workspace have no limit and
+ * behave like flash_fwd_f32: sequences short enough to be converted inside the attention kernel
+ * (flash_fwd_f32_workspace_bytes returns 0), head dims that are not a multiple of 8, tensors off a 16-byte
+ * boundary.
  * All calls on one GPU share that GPU's buffer: calls that may overlap in time on one GPU (different
  * streams, different threads) race on it and must be serialised by the caller.  Nothing in the
  * buffer needs clearing between calls: every byte a call reads was written by the same call.
@@ -169,9 +180,10 @@ int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o,
                          int64_t B, int64_t H, int64_t N, int64_t d,
                          float softmax_scale, int kernel_type, void* hip_stream);
 
-/* Workspace flash_fwd_f32_ws uses for this shape: 3 fp16 copies of B*H*N*d elements when d % 8 == 0,
- * 0 when the shape has no fast path, -1 (and an error text) when the shape or kernel type is
- * rejected.  Does not touch the GPU. */
+/* Workspace flash_fwd_f32_ws uses for this shape: the fp16 copies its conversion pass writes (two of
+ * B*H*N*d elements, three for the 128-rows-per-wave layout), 0 when the call converts inside the attention
+ * kernel (short sequences, d % 8 != 0), -1 (and an error text) when the shape or kernel type is rejected.
+ * Does not touch the GPU. */
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type);
 
 /*
@@ -183,8 +195,7 @@ int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d
 int flash_fwd_query(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type,
                     flash_launch_info* out);
 
-/* As flash_fwd_query, for the entry point `entry` (a flash_hip_entry): fp32 callers without a
- * workspace run the element-staging kernel (staging 0, three-slot LDS rings, never persistent). */
+/* As flash_fwd_query, for the entry point `entry` (a flash_hip_entry), assuming 16-byte-aligned tensors. */
 int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, int entry,
                           flash_launch_info* out);
 
@@ -196,8 +207,20 @@ const char* flash_kernel_type_name(int kernel_type);
  * failing call on the same thread. */
 const char* flash_hip_last_error(void);
 
-/* Library version, major*10000 + minor*100 + patch. */
+/* Library version, major*10000 + minor*100 + patch.  300: flash_launch_info unchanged since 200 (which
+ * appended `persistent`: callers built against 100 must be recompiled, the query functions write the
+ * whole structure). */
 int flash_hip_version(void);
+
+/*
+ * Diagnostics; no counterpart in the reference.  The library routes a call by a few switches that it
+ * reads from the environment ONCE, on the first call of the process (FLASH_HIP_PERSISTENT,
+ * FLASH_HIP_PERSISTENT_MAX_N, FLASH_HIP_WIDE_MAX_N, FLASH_HIP_TALL, FLASH_HIP_VEC_MAX_N: wave layout and
+ * kernel variant, for A/B measurements; every setting computes the same function).  This call reads them
+ * again, for harnesses that compare two settings inside one process.  Safe against calls in flight on
+ * other threads (each routes by the old or the new set as a whole).  Always returns FLASH_HIP_OK.
+ */
+int flash_hip_reload_switches(void);
 
 #ifdef __cplusplus
 }

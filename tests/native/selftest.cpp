@@ -310,7 +310,7 @@ static int bench_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps, int
 }
 
 // A/B of the persistent and the one-item-per-workgroup kernels, interleaved launch by launch in one
-// process on one device (FLASH_HIP_PERSISTENT is read by the library on every call).
+// process on one device (the library re-reads FLASH_HIP_PERSISTENT when asked to).
 static int ab_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps) {
   const size_t n = (size_t)(B * H * N * d);
   std::vector<float> x(std::min<size_t>(n, (size_t)8 * N * d));
@@ -337,6 +337,7 @@ static int ab_shape(int64_t B, int64_t H, int64_t N, int64_t d, int reps) {
   for (int i = 0; i < 2 * (reps + 3); ++i) {
     const int which = i & 1;
     setenv("FLASH_HIP_PERSISTENT", which ? "1" : "0", 1);
+    flash_hip_reload_switches();
     HIP_CHECK(hipEventRecord(e0, nullptr));
     flash_fwd_f16(dq, dk, dv, dout, B, H, N, d, scale, FLASH_KT_MMA_QREG_ASYNC, nullptr);
     HIP_CHECK(hipEventRecord(e1, nullptr));

@@ -67,13 +67,24 @@ def test_geometry_query_per_entry_point(fa):
     assert not ragged.persistent and ragged.sram_size == 2 * 3 * 64 * 256
     bf = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_BF16)
     assert bf == f16
+    # fp32 tensors converted inside the attention kernel (flash_fwd_f32): rows of a multiple of 8 elements
+    # are staged with 128-bit loads through registers (staging 1) by four waves x 64 query rows, whole
+    # tiles on the persistent kernel; other head dims stage element by element (staging 0)
     f32 = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_F32)
-    assert not f32.persistent and f32.staging == 0 and f32.sram_size == 2 * 3 * 64 * 256
+    assert f32.persistent and f32.staging == 1 and f32.sram_size == 2 * 4 * 64 * 256
     assert f32.grid_dim == f16.grid_dim and f32.block_dim == (64, 4)
-    # fp32 tensors through a workspace: the fp16 kernels with fp32 output, four waves beyond N = 512
-    ws = fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_F32_WS)
-    assert ws.persistent and ws.staging == 2 and ws.block_dim == (64, 4) and f16.block_dim == (64, 8)
-    assert fa.launch_info(4, 96, 512, 128, entry=fa.ENTRY_F32_WS).block_dim == (64, 8)
+    f32r = fa.launch_info(4, 96, 1000, 128, entry=fa.ENTRY_F32)
+    assert not f32r.persistent and f32r.staging == 1 and f32r.sram_size == 2 * 3 * 64 * 256
+    f32e = fa.launch_info(5, 12, 53, 69, fa.KernelType.naive1D, entry=fa.ENTRY_F32)
+    assert not f32e.persistent and f32e.staging == 0 and f32e.block_dim == (64, 4)
+    # fp32 tensors with a workspace: up to N = 2048 (768 for head dims up to 64) the same in-kernel
+    # conversion, beyond that the conversion pass and the fp16 kernels with fp32 output (four waves)
+    assert fa.launch_info(4, 96, 1024, 128, entry=fa.ENTRY_F32_WS) == f32
+    assert fa.launch_info(4, 96, 512, 128, entry=fa.ENTRY_F32_WS).staging == 1
+    ws = fa.launch_info(4, 96, 4096, 128, entry=fa.ENTRY_F32_WS)
+    assert ws.persistent and ws.staging == 2 and ws.block_dim == (64, 4)
+    assert fa.launch_info(4, 96, 4096, 128).block_dim == (64, 8)
+    assert fa.launch_info(16, 32, 512, 64, entry=fa.ENTRY_F32_WS).staging == 1
     assert fa.launch_info(16, 32, 2048, 64, entry=fa.ENTRY_F32_WS).tile_size == (64, 512, 64)
     with pytest.raises(ValueError, match="multiple of 8"):
         fa.launch_info(1, 1, 64, 50, fa.KernelType.mma_qreg, entry=fa.ENTRY_BF16)
@@ -139,11 +150,17 @@ def test_null_pointer_and_errors_through_raw_abi(fa):
 
 
 def test_fp32_workspace_size_query(fa):
-    """No GPU needed: three fp16 copies (256-byte granules) when rows have 16-byte chunks, else 0;
-    -1 with the reference's error text for shapes flash::forward rejects."""
+    """No GPU needed: the fp16 copies the conversion pass writes (256-byte granules) -- K and V, and Q as
+    well for the 128-rows-per-wave layout; 0 for shapes that are converted inside the attention kernel
+    (rows without 16-byte chunks, sequences up to the register-staging limit); -1 with the reference's
+    error text for shapes flash::forward rejects."""
     L = fa.lib()
-    assert L.flash_fwd_f32_workspace_bytes(4, 96, 4096, 128, 11) == 3 * 4 * 96 * 4096 * 128 * 2
-    assert L.flash_fwd_f32_workspace_bytes(1, 1, 3, 8, 0) == 3 * 256
+    assert L.flash_fwd_f32_workspace_bytes(4, 96, 4096, 128, 11) == 2 * 4 * 96 * 4096 * 128 * 2
+    assert L.flash_fwd_f32_workspace_bytes(16, 32, 2048, 64, 11) == 3 * 16 * 32 * 2048 * 64 * 2
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 2049, 8, 0) == 2 * ((2049 * 8 * 2 + 255) // 256 * 256)
+    assert L.flash_fwd_f32_workspace_bytes(4, 96, 2048, 128, 11) == 0
+    assert L.flash_fwd_f32_workspace_bytes(16, 32, 768, 64, 11) == 0
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 3, 8, 0) == 0
     assert L.flash_fwd_f32_workspace_bytes(5, 12, 53, 69, 0) == 0
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 50, 9) == 0
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 50, 11) == -1

@@ -98,9 +98,10 @@ TUNED = {
 @pytest.mark.parametrize("frag", sorted(TUNED))
 def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
     # three instantiations each: fp16 in/out, bfloat16 in/out, fp16 in with O written as fp32 (same loop
-    # structure, different matrix-instruction mnemonics and epilogues)
+    # structure, different matrix-instruction mnemonics and epilogues); the four-wave kernels also exist
+    # with fp32 K and V staged through registers ("Lb1": the same steps plus loads, conversions and LDS writes)
     ks = {n: l for n, l in kernels(asm_text).items() if frag in n}
-    assert len(ks) == 3, list(ks)
+    assert len(ks) == (4 if frag.startswith("3m16") else 3), list(ks)
     for name, lines in ks.items():
         per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
         loop = main_loop(lines, TUNED[frag][0] - per_step)
@@ -111,14 +112,23 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
         assert all(want in l for l in lines if "v_mfma_f32_16x16x32" in l), f"{name}: mixed operand kinds"
         assert n_mfma in (TUNED[frag][0], TUNED[frag][0] - per_step), (name, n_mfma)
         moves = [l for l in hot if l.startswith("v_accvgpr_")]
-        assert not moves, f"{name}: {len(moves)} VGPR<->AGPR moves in the main loop, e.g. {moves[:3]}"
+        d = 128 if "Li128E" in name else 64
+        nq = TUNED[frag][2]
+        base = nq * d * 3 // 8          # O^T: nq * d / 4 registers, Q: nq * d / 8
+        if "Lb1" in name and d == 128 and "m16pI" in name:
+            # persistent kernel: fp32 K/V tiles land in accumulation registers above the row sums and are read out of them for
+            # the conversion: reads of exactly those registers, never a write
+            assert all(m.startswith("v_accvgpr_read") for m in moves), (name, moves[:3])
+            landing = _acc_regs(" ".join(m.split(None, 1)[1].split(",")[1] for m in moves))
+            assert landing and min(landing) >= base + 4 * nq and len(landing) == 32, (name, sorted(landing))
+            loads = [l for l in hot if l.startswith("buffer_load")]
+            assert loads and all(_acc_regs(l.split(None, 1)[1].split(",")[0]) <= landing for l in loads), name
+        else:
+            assert not moves, f"{name}: {len(moves)} VGPR<->AGPR moves in the main loop, e.g. {moves[:3]}"
         assert not any("scratch_" in l or "buffer_store" in l for l in hot), name
         # one barrier per tile iteration
         assert sum(l.startswith("s_barrier") for l in hot) in (TUNED[frag][1], TUNED[frag][1] - 1), name
         # the row sums stay in their fixed accumulation registers, right behind O^T and Q
-        d = 128 if "Li128E" in name else 64
-        nq = TUNED[frag][2]
-        base = nq * d * 3 // 8          # O^T: nq * d / 4 registers, Q: nq * d / 8
         sums = {f"a[{base + 4 * q}:{base + 4 * q + 3}]" for q in range(nq)}
         n_sum = 0
         for l in hot:
@@ -176,6 +186,17 @@ def test_no_mfma_result_is_touched_before_its_latency_is_over(asm_text):
     assert mod.result_hazards(late) == []
     as_operand = early[:1] + ["v_mfma_f32_4x4x4_16b_f16 a[0:3], v[0:1], v[4:5], a[0:3]"]
     assert len(mod.result_hazards(as_operand)) == 1
+    # across a loop's back edge: the matrix instruction at the bottom of the loop, its reader at the header
+    loop = [".LBB0_1: ; Loop Header", "v_exp_f32_e32 v30, v1", "v_add_f32 v20, v21, v22", "s_nop 2",
+            "v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], a[0:3], v[0:3]", "s_add_i32 s0, s0, 1",
+            "s_cbranch_scc1 .LBB0_1", "s_nop 15", "s_endpgm"]
+    assert [(w, n) for _, _, w, n in mod.result_hazards(loop)] == [(2, 11)]
+    padded = loop[:5] + ["s_nop 9"] + loop[5:]
+    assert mod.result_hazards(padded) == []
+    # into an out-of-line block behind an unconditional branch (only reachable by following the branch)
+    far = ["v_mfma_f32_16x16x32_f16 v[0:3], v[8:11], a[0:3], v[0:3]", "s_cbranch_vccnz .LBB0_9", "s_nop 15",
+           "s_branch .LBB0_8", ".LBB0_9:", "v_mul_f32 v1, v1, v5", "s_branch .LBB0_8", ".LBB0_8:", "s_endpgm"]
+    assert [(w, n) for _, _, w, n in mod.result_hazards(far)] == [(1, 11)]
     names = 0
     for name, lines in mod.kernels(asm_text).items():
         names += 1
@@ -191,7 +212,9 @@ def test_lds_dma_base_register_is_set_and_used_undisturbed(asm_text):
     for name, lines in kernels(asm_text).items():
         ins = [l for l in lines if not l.startswith(".LBB")]
         loads = [i for i, l in enumerate(ins) if l.startswith("buffer_load") and l.rstrip().endswith("lds")]
-        if "m16" in name or "Lb0" not in name:
+        if "Lb1" in name:      # fp32 K/V: staged through registers, no global->LDS loads at all
+            assert not loads, name
+        elif "m16" in name:
             assert loads, name
         for i in loads:
             j = i - 1
@@ -214,3 +237,26 @@ def test_no_mfma_reads_a_register_written_just_before_it(asm_text):
             continue
         found = mod.hazards(lines, window=3)
         assert not found, (name, found[:4])
+
+
+def test_no_memory_instruction_reads_a_scalar_register_a_vector_instruction_just_wrote(asm_text):
+    """Buffer loads and stores read their descriptor and scalar offset from scalar registers; one that a
+    vector instruction (v_readfirstlane ...) wrote needs five wait states first.  The compiler pads the
+    memory instructions it issues itself, not the ones the kernels issue from inline asm."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("mfma_hazards", os.path.join(ROOT, "tools", "mfma_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = ["v_readfirstlane_b32 s8, v247", "s_lshl_b32 s8, s8, 1", "v_mul_f32 v1, v1, v5",
+             "buffer_load_dwordx4 a[60:63], v197, s[36:39], s8 offen"]
+    assert [w for _, _, w in mod.scalar_operand_hazards(fresh)] == [2]
+    assert mod.scalar_operand_hazards(fresh[:3] + ["s_nop 2"] + fresh[3:]) == []
+    desc = ["v_readfirstlane_b32 s38, v3", "s_nop 0", "buffer_load_dwordx4 v[0:3], v9, s[36:39], 0 offen lds"]
+    assert len(mod.scalar_operand_hazards(desc)) == 1
+    names = 0
+    for name, lines in mod.kernels(asm_text).items():
+        names += 1
+        found = mod.scalar_operand_hazards(lines)
+        assert not found, (name, found[:4])
+    assert names >= 16

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ATOL, RUNNER_SHAPES, TINY_SHAPE, assert_close, load_golden
+from conftest import ATOL, RTOL, RUNNER_SHAPES, TINY_SHAPE, assert_close, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,8 @@ def run_abi(fa, torch, q, k, v, kt, dtype, workspace=False):
     if workspace:
         assert dtype == torch.float32
         nbytes = L.flash_fwd_f32_workspace_bytes(B, H, N, d, int(kt))
-        assert nbytes == (3 * ((B * H * N * d * 2 + 255) // 256 * 256) if d % 8 == 0 else 0)
+        each = (B * H * N * d * 2 + 255) // 256 * 256     # one fp16 copy; 0, 2 or 3 of them by route
+        assert nbytes in ((0, 2 * each, 3 * each) if d % 8 == 0 else (0,)), nbytes
         ws = torch.full((max(nbytes, 1),), 0xFF, dtype=torch.uint8, device="cuda:0")
         rc = L.flash_fwd_f32_ws(tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out.data_ptr(), B, H, N, d,
                                 1.0 / np.sqrt(d), int(kt), ws.data_ptr() if nbytes else None, nbytes, stream)
@@ -47,6 +48,26 @@ def run_abi(fa, torch, q, k, v, kt, dtype, workspace=False):
     assert rc == 0, L.flash_hip_last_error()
     torch.cuda.synchronize()
     return out.float().cpu().numpy()
+
+
+class routing:
+    """Environment switches of the library's routing for the duration of a `with` block (the library reads
+    them once per process; flash_hip_reload_switches() makes it read them again)."""
+
+    def __init__(self, fa, monkeypatch, **env):
+        self.fa, self.mp, self.env = fa, monkeypatch, env
+
+    def __enter__(self):
+        for name, val in self.env.items():
+            self.mp.setenv(name, str(val))
+        self.fa.lib().flash_hip_reload_switches()
+        return self
+
+    def __exit__(self, *exc):
+        for name in self.env:
+            self.mp.delenv(name)
+        self.fa.lib().flash_hip_reload_switches()
+        return False
 
 
 def allowed(fa, kt, d):
@@ -100,40 +121,74 @@ def test_seeded_shapes_vs_oracle(fa, oracle, torch_gpu, shape):
     assert_close(o, ref, f"{shape} fp32 with workspace")
 
 
-def test_fp32_callers_many_items_per_workgroup(fa, oracle, torch_gpu):
-    """fp32 tensors through the workspace with more work items than workgroups: the persistent kernels
-    fetch the next item's Q as fp32 during the current item's epilogue (two landing phases at d = 128,
-    one at d = 64) and convert it behind the output stores; inputs that are not fp16-representable, so
-    the in-kernel rounding of Q is what is checked.  The 512-row-tile and N <= 512 shapes take Q from
-    the conversion pass instead."""
+def test_fp32_callers_many_items_per_workgroup(fa, oracle, torch_gpu, monkeypatch):
+    """fp32 tensors with more work items than workgroups, inputs that are not fp16-representable (so the
+    in-kernel rounding of Q, K and V is what is checked), through both routes of flash_fwd_f32_ws:
+      * conversion inside the attention kernel (the default at these lengths; staging 1): the persistent
+        kernel loads fp32 K/V tiles into registers, rounds them and writes the LDS image itself, and
+        fetches the next item's fp32 Q under the current item's last steps;
+      * the conversion pass into the workspace followed by the fp16 kernels with fp32 output
+        (FLASH_HIP_VEC_MAX_N=0 routes every length there), whose four-wave layout also reads Q as fp32.
+    """
     torch = torch_gpu
-    for shape in ((2, 150, 768, 128), (2, 300, 768, 64), (2, 300, 1024, 64), (3, 200, 512, 128)):
-        rng = np.random.default_rng(shape[1] + shape[2])
-        q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.21) for _ in range(3))
-        o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32, workspace=True)
+    for vec_max_n, staging in ((None, 1), (0, 2)):
+        env = {} if vec_max_n is None else {"FLASH_HIP_VEC_MAX_N": vec_max_n}
+        with routing(fa, monkeypatch, **env):
+            for shape in ((2, 150, 768, 128), (2, 300, 768, 64), (2, 300, 1024, 64), (3, 200, 512, 128)):
+                if vec_max_n is None and shape == (2, 300, 1024, 64):
+                    continue        # beyond the d = 64 register-staging limit: already the pass route
+                assert fa.launch_info(*shape, entry=fa.ENTRY_F32_WS).staging == staging
+                rng = np.random.default_rng(shape[1] + shape[2])
+                q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.21) for _ in range(3))
+                o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32, workspace=True)
+                B, H = shape[:2]
+                for (b, h) in sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2), (0, 1), (B - 1, H - 2)}):
+                    ref = oracle.attn_naive(*(oracle.round_f16(x[b:b + 1, h:h + 1]) for x in (q, k, v)))[0, 0]
+                    assert_close(o[b, h], ref, f"fp32, staging {staging}, {shape} head {(b, h)}")
+
+
+def test_fp32_register_staged_route(fa, oracle, torch_gpu):
+    """flash_fwd_f32 on rows of a multiple of 8 elements (staging 1): whole tiles on the persistent kernel,
+    ragged N with one item per workgroup and a key mask, head dims below the tile width (chunks beyond d
+    read as zeros), a one-tile sequence, many items per workgroup; inputs not fp16-representable."""
+    torch = torch_gpu
+    for shape in ((1, 3, 2048, 128), (2, 5, 1000, 128), (1, 2, 256, 120), (2, 3, 700, 40), (1, 4, 64, 8),
+                  (1, 3, 33, 64), (1, 700, 256, 64), (2, 7, 1536, 64), (1, 2, 4096, 128)):
+        info = fa.launch_info(*shape, entry=fa.ENTRY_F32)
+        assert info.staging == 1 and info.persistent == (shape[2] % 256 == 0) and info.block_dim == (64, 4)
+        rng = np.random.default_rng(shape[2] + shape[3])
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.13) for _ in range(3))
+        o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32)
         B, H = shape[:2]
-        for (b, h) in sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2), (0, 1), (B - 1, H - 2)}):
+        for (b, h) in sorted({(0, 0), (B - 1, H - 1), (B // 2, H // 2)}):
             ref = oracle.attn_naive(*(oracle.round_f16(x[b:b + 1, h:h + 1]) for x in (q, k, v)))[0, 0]
-            assert_close(o[b, h], ref, f"fp32 through workspace {shape} head {(b, h)}")
+            assert_close(o[b, h], ref, f"fp32 register-staged {shape} head {(b, h)}")
 
 
-def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gpu):
+def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gpu, monkeypatch):
     """fp32 tensors that are NOT fp16-representable: the conversion pass into the workspace and the
     in-kernel conversion round the same way (to nearest even), so both agree with the oracle on the
     rounded inputs and with each other far inside the bar; a short workspace is refused; no workspace
     means the in-kernel path."""
     torch = torch_gpu
     L = fa.lib()
-    for shape in ((2, 3, 512, 128), (1, 4, 333, 64), (2, 2, 1024, 72)):
-        B, H, N, d = shape
-        rng = np.random.default_rng(N)
-        q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.37) for _ in range(3))
-        ref = oracle.attn_naive(*(oracle.round_f16(x) for x in (q, k, v)))
-        a = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32)
-        b = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32, workspace=True)
-        assert_close(a, ref, f"{shape} in-kernel conversion")
-        assert_close(b, ref, f"{shape} workspace conversion")
-        assert np.abs(a - b).max() <= 1e-3   # two kernel families: different (in-bar) roundings of Q*scale
+    with routing(fa, monkeypatch, FLASH_HIP_VEC_MAX_N=0):    # a workspace means the conversion pass at any length
+        for shape in ((2, 3, 512, 128), (1, 4, 333, 64), (2, 2, 1024, 72)):
+            B, H, N, d = shape
+            rng = np.random.default_rng(N)
+            q, k, v = (rng.standard_normal(shape).astype(np.float32) * np.float32(1.37) for _ in range(3))
+            ref = oracle.attn_naive(*(oracle.round_f16(x) for x in (q, k, v)))
+            a = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32)
+            b = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32, workspace=True)
+            assert_close(a, ref, f"{shape} in-kernel conversion")
+            assert_close(b, ref, f"{shape} workspace conversion")
+            assert np.abs(a - b).max() <= 1e-3   # same roundings of the inputs, different order of fp32 sums
+        _workspace_argument_errors(fa, torch, shape)
+
+
+def _workspace_argument_errors(fa, torch, shape):
+    L = fa.lib()
+    B, H, N, d = shape
     tq = torch.randn(shape, device="cuda:0")
     out = torch.empty_like(tq)
     need = L.flash_fwd_f32_workspace_bytes(B, H, N, d, 11)
@@ -150,11 +205,12 @@ def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gp
 
 def test_seeded_fuzz_over_shapes_types_and_entry_points(fa, oracle, torch_gpu):
     """Forty pseudo-random cases (fixed seed): batch, heads, sequence length (1..900, tile edges
-    favoured), head dim (1..128), kernel type, tensor dtype / entry point, input scale.  The scale stays
-    at or below one standard deviation: the absolute bar is stated for unit-scale inputs (the fp16
-    rounding of P alone is 2^-11 of |V|, and the rounding of Q * scale to fp16 moves a score by 2^-11 of
-    its magnitude, so the error grows with the cube of the input scale; at 1.5 standard deviations a case
-    lands at 2.03e-3 absolute while still inside 2e-3 + 1e-2 |ref|).  Large scores have their own test."""
+    favoured), head dim (1..128), kernel type, tensor dtype / entry point, input scale 0.25 ... 1.5
+    standard deviations.  Up to unit scale both forms of the bar apply (max-abs 2e-3 and the allclose
+    form); at 1.5 standard deviations the outputs themselves are larger and the bar is the allclose form,
+    |res - ref| <= 2e-3 + 1e-2 |ref|, as the reference's runner states its own (main.cpp:49).  The one
+    rounding inside the kernel is that of P to fp16 (2^-11 of |V| per term); Q, K and V reach the matrix
+    cores as stored.  Large scores have their own test."""
     torch = torch_gpu
     rng = np.random.default_rng(20240611)
     edges = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 767, 768]
@@ -167,11 +223,16 @@ def test_seeded_fuzz_over_shapes_types_and_entry_points(fa, oracle, torch_gpu):
         if not allowed(fa, kt, d):
             continue
         mode = int(rng.integers(0, 3))          # 0 fp16, 1 fp32, 2 fp32 with workspace
-        scale = float(rng.choice([0.25, 0.5, 1.0]))
+        scale = float(rng.choice([0.25, 0.5, 1.0, 1.5]))
         q, k, v = (oracle.round_f16((rng.standard_normal((B, H, N, d)) * scale).astype(np.float32)) for _ in range(3))
         ref = oracle.attn_naive(q, k, v)
         o = run_abi(fa, torch, q, k, v, kt, torch.float16 if mode == 0 else torch.float32, workspace=(mode == 2))
-        assert_close(o, ref, f"fuzz case {done}: {(B, H, N, d)} {kt.name} mode {mode} scale {scale}")
+        what = f"fuzz case {done}: {(B, H, N, d)} {kt.name} mode {mode} scale {scale}"
+        if scale <= 1.0:
+            assert_close(o, ref, what)
+        else:
+            err = np.abs(o.astype(np.float64) - ref)
+            assert not np.isnan(o).any() and (err <= ATOL + RTOL * np.abs(ref)).all(), f"{what}: max-abs {err.max():.3e}"
         done += 1
 
 
@@ -192,9 +253,8 @@ def test_forced_rescale_spike(fa, oracle, torch_gpu, monkeypatch):
         ((2, 300, 1024, 64), {}),                                 # 1200 items of 512 rows
     ]
     for shape, env in cases:
+      with routing(fa, monkeypatch, **env):
         B, H, N, d = shape
-        for name, val in env.items():
-            monkeypatch.setenv(name, val)
         rng = np.random.default_rng(7)
         q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
         spikes = [(5, 200, 6.0), (37, 449, 9.0), (300, N - 1, 12.0), (301, 64, 8.0), (N - 41, 3, 7.0), (N - 1, N - 2, 10.0)]
@@ -206,19 +266,22 @@ def test_forced_rescale_spike(fa, oracle, torch_gpu, monkeypatch):
         for (b, h) in heads:
             ref = oracle.attn_naive(*(x[b:b + 1, h:h + 1] for x in (q, k, v)))[0, 0]
             assert_close(o[b, h], ref, f"spiked keys {shape} {env} head {(b, h)}")
-        for name in env:
-            monkeypatch.delenv(name)
+        # fp32 tensors: conversion inside the attention kernel (register staging) on the same spiked data
+        if N <= 768:
+            o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float32)
+            for (b, h) in heads:
+                ref = oracle.attn_naive(*(x[b:b + 1, h:h + 1] for x in (q, k, v)))[0, 0]
+                assert_close(o[b, h], ref, f"spiked keys, fp32 register-staged {shape} {env} head {(b, h)}")
 
 
 def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
     """Scores with a standard deviation of ~90 in exp2 units (|q.k|/sqrt(d) of several hundred): the
     exp2 domain must stay finite and the reference updates must keep up.
 
-    Q reaches the matrix cores exactly (the scale is applied to the fp32 scores), so the
-    result is compared with the unperturbed oracle, evaluated in float64.  At this spread the softmax is
-    an argmax whose near-ties amplify the fp32 rounding of the scores themselves (one part in 10^7 of a
-    score of several hundred moves a weight by 10^-4), so a small share of rows may sit just above the
-    bar; none may be far off."""
+    Q reaches the matrix cores exactly (the scale is applied to the fp32 scores), so the result is
+    compared with the unperturbed formula, evaluated in float64, at the plain bar.  (At this spread the
+    softmax is close to an argmax; what fp32 score arithmetic alone costs is measured beside it, the fp32 CPU
+    oracle against float64 on the same inputs: a few 1e-5, far below the bar.)"""
     B, H = 1, 1
     for N, d in ((384, 64), (384, 128), (512, 64), (512, 128)):   # ragged and persistent kernels
         rng = np.random.default_rng(11 + d)
@@ -226,18 +289,21 @@ def test_large_scores_do_not_overflow(fa, oracle, torch_gpu):
         k = (rng.standard_normal((B, H, N, d)) * 8).astype(np.float32)
         v = rng.standard_normal((B, H, N, d)).astype(np.float32)
         q, k, v = (oracle.round_f16(x) for x in (q, k, v))
-        o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float16)
-        assert np.isfinite(o).all()
-        err_rows = np.abs(o - oracle.attn_numpy(q, k, v)).max(axis=-1)
-        print(f"large scores N={N} d={d}: {(err_rows > ATOL).mean():.3f} of the rows above {ATOL}, max {err_rows.max():.3e}")
-        assert (err_rows > ATOL).mean() <= 0.02 and err_rows.max() <= 1e-2, (
-            f"N={N} d={d}: {(err_rows > ATOL).mean():.3f} of the rows off, max {err_rows.max():.3e}")
+        exact = oracle.attn_numpy(q, k, v)
+        fp32_rows = np.abs(oracle.attn_naive(q, k, v) - exact).max(axis=-1)     # what fp32 scores alone cost
+        for dtype in (torch_gpu.float16, torch_gpu.float32):
+            o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, dtype)
+            assert np.isfinite(o).all()
+            err_rows = np.abs(o - exact).max(axis=-1)
+            print(f"large scores N={N} d={d} {dtype}: kernel max-abs {err_rows.max():.3e} (bar {ATOL}); "
+                  f"fp32 oracle vs float64 max-abs {fp32_rows.max():.3e}")
+            assert err_rows.max() <= ATOL, f"N={N} d={d} {dtype}: {(err_rows > ATOL).sum()} rows above the bar, max {err_rows.max():.3e}"
+            assert fp32_rows.max() <= ATOL / 10
 
 
 def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monkeypatch):
     """The persistent d = 128 kernel exists in two wave layouts (four waves x 64 query rows, eight waves
-    x 32) and the library picks by sequence length.  FLASH_HIP_WIDE_MAX_N (read on every call) forces
-    either one: both must meet the bar on the same inputs, for fp16 and for fp32 tensors through the
+    x 32) and the library picks by sequence length.  FLASH_HIP_WIDE_MAX_N forces either one: both must meet the bar on the same inputs, for fp16 and for fp32 tensors through the
     workspace (fp32 output), with several items per workgroup at the second shape."""
     torch = torch_gpu
     for shape in ((1, 5, 768, 128), (3, 200, 512, 128)):
@@ -247,14 +313,15 @@ def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monke
         ref = {bh: oracle.attn_naive(*(x[bh[0]:bh[0] + 1, bh[1]:bh[1] + 1] for x in (q, k, v)))[0, 0] for bh in heads}
         outs = []
         for limit, waves in (("0", 4), ("1000000", 8)):
-            monkeypatch.setenv("FLASH_HIP_WIDE_MAX_N", limit)
-            assert fa.launch_info(*shape).block_dim == (64, waves)
-            for dtype, ws in ((torch.float16, False), (torch.float32, True)):
-                o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
-                for bh in heads:
-                    assert_close(o[bh], ref[bh], f"{shape} head {bh} {waves} waves {dtype}")
-                outs.append(o)
-        monkeypatch.delenv("FLASH_HIP_WIDE_MAX_N")
+            # (FLASH_HIP_VEC_MAX_N=0: fp32 tensors with a workspace take the conversion pass, whose fp16
+            # kernels are the ones that come in these two layouts)
+            with routing(fa, monkeypatch, FLASH_HIP_WIDE_MAX_N=limit, FLASH_HIP_VEC_MAX_N=0):
+                assert fa.launch_info(*shape).block_dim == (64, waves)
+                for dtype, ws in ((torch.float16, False), (torch.float32, True)):
+                    o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
+                    for bh in heads:
+                        assert_close(o[bh], ref[bh], f"{shape} head {bh} {waves} waves {dtype}")
+                    outs.append(o)
         # same arithmetic per query row in both layouts (only the wave-wide decision to move a reference
         # can fall differently): the fp16 results agree far inside the bar
         assert np.abs(outs[0] - outs[2]).max() <= 2e-4, f"{shape}: the two layouts differ"
@@ -262,7 +329,7 @@ def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monke
 
 def test_tall_layout_of_the_persistent_d64_kernel(fa, oracle, torch_gpu, monkeypatch):
     """Head dims up to 64 with whole 512-row query tiles run with 128 query rows per wave (tile_q 512);
-    FLASH_HIP_TALL=0 (read on every call) keeps them on the 64-rows-per-wave layout.  Both must meet the
+    FLASH_HIP_TALL=0 keeps them on the 64-rows-per-wave layout.  Both must meet the
     bar on the same inputs: fp16, fp32 through the workspace, a head dim below the tile width, and a
     shape with several items per workgroup."""
     torch = torch_gpu
@@ -273,19 +340,19 @@ def test_tall_layout_of_the_persistent_d64_kernel(fa, oracle, torch_gpu, monkeyp
         ref = {bh: oracle.attn_naive(*(x[bh[0]:bh[0] + 1, bh[1]:bh[1] + 1] for x in (q, k, v)))[0, 0] for bh in heads}
         outs = []
         for flag, tile_q in (("0", 256), ("1", 512)):
-            monkeypatch.setenv("FLASH_HIP_TALL", flag)
-            assert fa.launch_info(*shape).tile_size[1] == tile_q
-            for dtype, ws in ((torch.float16, False), (torch.float32, True)):
-                o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
-                for bh in heads:
-                    assert_close(o[bh], ref[bh], f"{shape} head {bh} tile_q {tile_q} {dtype}")
-                outs.append(o)
-        monkeypatch.delenv("FLASH_HIP_TALL")
+            with routing(fa, monkeypatch, FLASH_HIP_TALL=flag, FLASH_HIP_VEC_MAX_N=0):
+                assert fa.launch_info(*shape).tile_size[1] == tile_q
+                for dtype, ws in ((torch.float16, False), (torch.float32, True)):
+                    o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
+                    for bh in heads:
+                        assert_close(o[bh], ref[bh], f"{shape} head {bh} tile_q {tile_q} {dtype}")
+                    outs.append(o)
         assert np.abs(outs[0] - outs[2]).max() <= 2e-4, f"{shape}: the two layouts differ"
 
 
 # ---- full-size configurations: size-independent properties + sampled heads vs the oracle ----------
-FULL = [(4, 96, 1024, 128), (16, 32, 2048, 64), (4, 96, 4096, 128)]
+# BASELINE configurations and the short end of the reference's sequence sweep (benchmarks/bench.py:91)
+FULL = [(4, 96, 512, 128), (4, 96, 1024, 128), (4, 96, 2048, 128), (16, 32, 2048, 64), (4, 96, 4096, 128)]
 
 
 @pytest.mark.parametrize("shape", FULL, ids=str)

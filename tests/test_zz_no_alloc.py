@@ -29,8 +29,10 @@ def test_static_scratch_entry_matches_workspace_entry(fa, oracle):
     assert torch.cuda.is_available()
     L = fa.lib()
     rng = np.random.default_rng(2024)
-    # second call smaller than the first: stale contents of the shared buffer must not leak into it
-    for shape in ((2, 4, 1024, 128), (1, 3, 300, 64)):
+    # second call smaller than the first: stale contents of the shared buffer must not leak into it.  Both
+    # shapes are long enough to take the conversion pass (the route that uses the scratch: N > 2048, or
+    # N > 768 for head dims up to 64, where Q is converted by the pass as well)
+    for shape in ((1, 4, 4096, 128), (1, 3, 1024, 64)):
         B, H, N, d = shape
         host = [rng.standard_normal(shape).astype(np.float32) * np.float32(1.1) for _ in range(3)]
         q, k, v = (torch.from_numpy(x).to("cuda:0") for x in host)
@@ -43,7 +45,7 @@ def test_static_scratch_entry_matches_workspace_entry(fa, oracle):
         free_before = torch.cuda.mem_get_info()[0]
         assert _call(L, torch, "flash_fwd_f32_static", (q, k, v, o_st), shape) == 0, L.flash_hip_last_error()
         torch.cuda.synchronize()
-        assert torch.cuda.mem_get_info()[0] == free_before or shape[2] == 1024   # (first call may load code)
+        assert torch.cuda.mem_get_info()[0] == free_before or shape[2] == 4096   # (first call may load code)
         assert _call(L, torch, "flash_fwd_f32_ws", (q, k, v, o_ws), shape, ws) == 0, L.flash_hip_last_error()
         torch.cuda.synchronize()
         assert torch.equal(o_st, o_ws), f"{shape}: static-scratch output differs from the workspace entry"
@@ -56,13 +58,18 @@ def test_static_scratch_entry_rejects_what_does_not_fit(fa):
 
     L = fa.lib()
     t = torch.zeros(16, device="cuda:0")
-    # (1, 16, 4096, 128) is exactly the limit (8 Mi elements); one more head is over it
-    over = (1, 17, 4096, 128)
+    # K and V copies at d = 128: (1, 24, 4096, 128) is exactly the limit (12 Mi elements); one more head is over
+    over = (1, 25, 4096, 128)
     rc = L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), *over, 0.1, 11, None)
     assert rc == -1
     msg = L.flash_hip_last_error().decode()
     assert "flash_fwd_f32_static" in msg and str(48 << 20) in msg and "flash_fwd_f32_ws" in msg
-    assert L.flash_fwd_f32_workspace_bytes(1, 16, 4096, 128, 11) == 48 << 20
+    assert L.flash_fwd_f32_workspace_bytes(1, 24, 4096, 128, 11) == 48 << 20
+    # Q, K and V copies for the 128-rows-per-wave layout: 8 Mi elements
+    assert L.flash_fwd_f32_workspace_bytes(1, 32, 4096, 64, 11) == 48 << 20
+    assert L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 33, 4096, 64, 0.1, 11, None) == -1
+    # sequences short enough to be converted inside the attention kernel use no scratch and have no limit
+    assert L.flash_fwd_f32_workspace_bytes(64, 96, 2048, 128, 11) == 0
     # errors of the plain entry points are kept
     assert L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 1, 64, 200, 0.1, 11, None) == -2
 
@@ -75,7 +82,7 @@ def test_static_scratch_entry_is_capturable_in_a_hip_graph(fa, oracle):
     import torch
 
     L = fa.lib()
-    shape = (2, 3, 768, 128)
+    shape = (1, 3, 2304, 128)
     rng = np.random.default_rng(77)
     host = [rng.standard_normal(shape).astype(np.float32) for _ in range(6)]
     q, k, v = (torch.from_numpy(x).to("cuda:0") for x in host[:3])
@@ -95,3 +102,24 @@ def test_static_scratch_entry_is_capturable_in_a_hip_graph(fa, oracle):
         torch.cuda.synchronize()
         ref = oracle.attn_naive(*(oracle.round_f16(x) for x in host[base:base + 3]))
         assert_close(o.cpu().numpy(), ref, f"graph replay of the static-scratch entry, inputs {base}")
+
+
+def test_static_scratch_entry_takes_unaligned_tensors_of_any_size(fa, oracle):
+    """Tensors that start off a 16-byte boundary never use the scratch (they are staged element by element
+    inside the attention kernel), so the size limit does not apply to them: a shape over the limit is
+    accepted and computed, like flash_fwd_f32 would."""
+    import torch
+
+    L = fa.lib()
+    shape = (1, 25, 4096, 128)
+    B, H, N, d = shape
+    n = B * H * N * d
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    bufs = [torch.randn(n + 8, device="cuda:0", generator=gen) for _ in range(3)] + [torch.zeros(n + 8, device="cuda:0")]
+    views = [b[1:1 + n].view(shape) for b in bufs]
+    assert all(t.data_ptr() % 16 == 4 for t in views)
+    assert _call(L, torch, "flash_fwd_f32_static", views, shape) == 0, L.flash_hip_last_error()
+    torch.cuda.synchronize()
+    h = H - 1
+    ref = oracle.attn_naive(*(oracle.round_f16(t[:, h:h + 1].cpu().numpy()) for t in views[:3]))[0, 0]
+    assert_close(views[3][0, h].cpu().numpy(), ref, "unaligned tensors over the scratch limit, last head")
