@@ -5,14 +5,17 @@
 
 One "step" = one forward pass of the native kernel over one synthetic batch that is already
 resident in HBM.  The default workload is the headline configuration of BASELINE.json's metric
-(fp16, B=8, H=96, N=4096, d=128 per GPU: B=64 over 8 GPUs is configs[4]); `--workload gpt3_1k` is configs[1] (N=1024) and `--workload
-d64` is the small-head configuration (16, 32, 2048, 64).  With N > 1 GPUs (launched through
-torch.distributed.run, one rank per GPU) every rank owns its own batch of the same shape — the
-batch x heads axis is what shards, there is no collective on the data path — so scaling is weak and
-`value` is the sum over ranks of FLOPs / max-over-ranks time.
+(fp16, B=8, H=96, N=4096, d=128 per GPU: B=64 over 8 GPUs is configs[4]); `--workload gpt3_1k` is configs[1]
+(N=1024) and `--workload d64` is the small-head configuration (16, 32, 2048, 64).  With N > 1 GPUs there is
+one rank process per GPU: `python bench.py --gpus N` starts them itself, and under a launcher such as
+torch.distributed.run the script is a rank.  Every rank owns its own batch of the same shape -- the
+batch x heads axis is what shards, there is no collective on the data path -- so scaling is weak and
+`value` is the sum over ranks of FLOPs / max-over-ranks time; the line also carries every rank's own kernel
+time (`ranks`), so that launch skew between GPUs shows.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      dominant kernel vs. the dense fp16 MFMA peak (HIP events on the launch stream)
+  roofline      dominant kernel vs. the dense fp16 MFMA peak (HIP events on the launch stream): the mean
+                over the timed region and the median of individually timed launches
   cpu_baseline  the CPU oracle (OpenMP, fp32) timed on a bounded head sample of the same workload
   parity        max-abs error of one head of the timed output against the CPU oracle
 """
@@ -107,6 +110,9 @@ def launch_ranks(n_ranks):
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # RCCL shares device buffers between the rank processes through IPC handles; the driver of these
+        # machines only supports the dmabuf kind, which this selects (the legacy kind fails with
+        # "hipIpcGetMemHandle: invalid argument").  The attention path itself shares nothing between ranks.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
@@ -214,10 +220,28 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
+    # the same launch timed one at a time (an event pair around each, all enqueued back to back, one
+    # synchronisation at the end): the median is insensitive to a slow first launch or a clock dip
+    n_single = max(20, min(args.steps, 200))
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_single)]
+    for e0, e1 in pairs:
+        e0.record()
+        fa.forward(q, k, v, kt, out=o, sync=False)
+        e1.record()
+    torch.cuda.synchronize(dev)
+    singles = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)
+    kernel_ms_median = singles[len(singles) // 2]
+
+    rank_ms = [kernel_ms]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        cpu_or_dev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=cpu_or_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([kernel_ms], device=cpu_or_dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) for x in every]
 
     gather = None
     if args.gather_chunks > 0:
@@ -309,6 +333,8 @@ def main():
                 "peak": PEAK_TFLOPS_FP16_DENSE,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_FP16_DENSE, 4),
+                # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes of this workload
+                # (profiles/traffic.json names the pass); not re-measured by this run
                 "traffic": measured_traffic(args.workload),
                 # ns: the wave layout the library picked (m16 = 4 waves x 64 query rows, m16w = 8 x 32, m16x = 4 x 128)
                 "kernel": "flash_hip::{ns}::attn_fwd_kernel_m16{}<{}, {}>".format(
@@ -319,8 +345,14 @@ def main():
                     len(ns), ns, 20 if pers else 19, "p" if pers else "", 128 if d > 64 else 64,
                     "DF16_" if args.dtype == "fp16" else "NS0_8bf16_outE"),
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_median": round(kernel_ms_median, 4),
+                "kernel_ms_median_of": n_single,
+                "frac_at_median": round(flops / (kernel_ms_median * 1e-3) / 1e12 / PEAK_TFLOPS_FP16_DENSE, 4),
                 "algorithmic_flops_per_launch": flops,
             },
+            # every rank's mean kernel time over the timed region: the spread is launch skew / device variation
+            "ranks": {"kernel_ms": [round(x, 4) for x in rank_ms], "min": round(min(rank_ms), 4),
+                      "max": round(max(rank_ms), 4)},
         }
         # parity of the timed output (one head) and the CPU baseline: rank 0, single-GPU runs only
         if world == 1:
@@ -334,6 +366,12 @@ def main():
             err = float(np.abs(o[B - 1, H - 1].float().cpu().numpy() - ref[0, 0]).max())
             bar = 2e-3 if args.dtype == "fp16" else 1.6e-2
             line["parity"] = {"max_abs_vs_cpu_oracle": err, "bar": bar, "ok": bool(err <= bar)}
+            if not err <= bar:
+                # a rate measured on a wrong result is no measurement: no JSON line, non-zero exit
+                sys.stderr.write(f"bench.py: parity FAILED: max-abs {err:.3e} against the CPU oracle exceeds {bar}\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                sys.exit(1)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(orc, shape)
         if secondary is not None:

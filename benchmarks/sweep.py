@@ -17,7 +17,8 @@ Rows
   mma_qreg_async     torch.ops.pyflash.mma_qreg_async -> native kernel
   torch_flash_v2     torch.nn.functional.scaled_dot_product_attention in fp16 (whatever backend
                      PyTorch-ROCm selects)
-  mma_qreg_async_fp32  the same op on fp32 tensors (conversion pass into scratch + fp16 kernel, fp32 out)
+  mma_qreg_async_fp32  the same op on fp32 tensors (converted inside the attention kernel up to N = 2048, by a
+                       conversion pass into scratch beyond; fp32 out)
   mma_qreg_async_bf16  the same op on bfloat16 tensors
 
 Two timing columns per row: `ms` = average of back-to-back calls between two HIP events, and
@@ -74,7 +75,7 @@ def main():
         ("mma_qreg_vld", pyflash.mma_qreg_vld),
         ("mma_qreg_async", pyflash.mma_qreg_async),
         ("torch_flash_v2", F.scaled_dot_product_attention),
-        # the reference's own tensor dtype: fp32 in, fp32 out (conversion pass + fp16 kernel)
+        # the reference's own tensor dtype: fp32 in, fp32 out
         ("mma_qreg_async_fp32", lambda q, k, v: pyflash.mma_qreg_async(q32, k32, v32)),
         # bfloat16 tensors: the same kernels with bfloat16 matrix instructions
         ("mma_qreg_async_bf16", lambda q, k, v: pyflash.mma_qreg_async(qb, kb, vb)),

@@ -29,6 +29,7 @@ repository; only numbers are.  Needs /root/reference, i.e. the build container:
 """
 import argparse
 import ast
+import hashlib
 import math
 import os
 import sys
@@ -39,6 +40,8 @@ import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE_BENCH = "/root/reference/benchmarks/bench.py"
+# sha256 of ast.dump() of the reference's manual_attn definition (benchmarks/bench.py:39-43)
+MANUAL_ATTN_AST_SHA256 = "e60a531a6ae571cfec1cafba1f249a3207275a44d66ab87116fda47b1bc3a73b"
 
 # (B, H, N, d), heads kept
 CASES = [
@@ -64,8 +67,21 @@ def load_reference_manual_attn(path=REFERENCE_BENCH):
     if len(defs) != 1:
         raise RuntimeError(f"expected one top-level manual_attn in {path}, found {len(defs)}")
     node = defs[0]
+    # The text is executed, so it is pinned first: its syntax tree must be the one this script was written
+    # against (digest below), and may hold nothing but arithmetic, attribute access and calls.  Anything
+    # else in those lines is refused before it runs, and the function gets no builtins.
+    digest = hashlib.sha256(ast.dump(node).encode()).hexdigest()
+    if digest != MANUAL_ATTN_AST_SHA256:
+        raise RuntimeError(f"{path}: manual_attn is not the definition the fixtures were made from "
+                           f"(syntax-tree digest {digest}); review it and update MANUAL_ATTN_AST_SHA256")
+    allowed = (ast.FunctionDef, ast.arguments, ast.arg, ast.Assign, ast.Return, ast.BinOp, ast.UnaryOp, ast.Call,
+               ast.keyword, ast.Attribute, ast.Name, ast.Constant, ast.Load, ast.Store, ast.MatMult, ast.Mult,
+               ast.Div, ast.USub)
+    for sub in ast.walk(node):
+        if not isinstance(sub, allowed):
+            raise RuntimeError(f"{path}: unexpected {type(sub).__name__} inside manual_attn")
     module = ast.Module(body=[node], type_ignores=[])
-    env = {"math": math, "torch": torch, "F": F}
+    env = {"__builtins__": {}, "math": math, "torch": torch, "F": F}
     exec(compile(module, path, "exec"), env)
     return env["manual_attn"], (node.lineno, node.end_lineno)
 

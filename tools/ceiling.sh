@@ -7,6 +7,9 @@
 # tools/summarize_ceiling.py condenses the output into profiles/r2_ceiling.json.
 set -o pipefail
 cd "$(dirname "$0")/.."
+# every loop below runs on the left of `| tee`: its exit status is PIPESTATUS[0], checked after each one, so
+# that a failed or crashed pass stops the script instead of leaving a partial run to be summarized
+check() { [ "$1" -eq 0 ] || { echo "ceiling.sh: $2 failed" >&2; exit 1; }; }
 MASKS="0 1 2 4 8 16 32 64 127"
 SHAPE="8 96 4096 128"
 if [ "$1" = build ]; then
@@ -31,14 +34,17 @@ for m in $MASKS; do
   # (the harness's own parity check fails on purpose here: only the timing line is kept; a crash leaves no such line)
   { LD_LIBRARY_PATH=gpurun_tmp/ko/$m timeout -k 10 120 tests/native/selftest bench $SHAPE 40 11 2>&1 || true; } | grep sustained | sed "s|^|[knockout $m] |" || exit 1
   LD_LIBRARY_PATH=gpurun_tmp/ko/$m timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/ko$m -o p -- tests/native/selftest bench $SHAPE 5 11 > $OUT/ko$m.log 2>&1
-  grep -q sustained $OUT/ko$m.log || { tail $OUT/ko$m.log; exit 1; }
+  grep -q sustained $OUT/ko$m.log || { tail $OUT/ko$m.log >&2; exit 1; }
 done | tee $OUT/knockout.log
+check ${PIPESTATUS[0]} "a knock-out pass"
 # the two wave layouts of the same kernel on the headline shape (FLASH_HIP_WIDE_MAX_N routes any N to the eight-wave one)
 for wide in 2048 1000000; do
   FLASH_HIP_WIDE_MAX_N=$wide timeout -k 10 120 tests/native/selftest bench $SHAPE 40 11 2>&1 | grep sustained | sed "s|^|[wide_max_n $wide] |" || exit 1
   FLASH_HIP_WIDE_MAX_N=$wide timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/wide$wide -o p -- tests/native/selftest bench $SHAPE 5 11 > $OUT/wide$wide.log 2>&1 || { tail $OUT/wide$wide.log; exit 1; }
 done | tee $OUT/layouts.log
+check ${PIPESTATUS[0]} "a wave-layout pass"
 for f in mfma_clock issue_cost lds_issue_cost; do
   echo "== $f"
   timeout -k 10 200 gpurun_tmp/mb/$f 2>&1 || exit 1
 done | tee $OUT/microbench.log
+check ${PIPESTATUS[0]} "a microbenchmark"
