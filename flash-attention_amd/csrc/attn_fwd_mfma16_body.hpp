@@ -46,6 +46,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FLASH_KNOCKOUT 0
 #endif
 constexpr int kKnock = FLASH_KNOCKOUT;
+// Comparison builds (-DFLASH_ROWSUM_DOT2): in the eight-wave layout the row sums are taken on the vector ALU
+// (v_dot2_f32_f16 of every packed pair of probabilities with ones, fp32 accumulation, one partial sum per
+// lane) instead of on the matrix pipe.
+#if defined(FLASH_ROWSUM_DOT2)
+constexpr bool kRowsumDot2 = FLASH_M16_ROWS == 32;
+#else
+constexpr bool kRowsumDot2 = false;
+#endif
 
 constexpr int kQ16 = kRowsPerWave / 16;  // 16-row query blocks per wave
 constexpr int kRing = 3;                 // tiles per LDS ring
@@ -224,7 +232,11 @@ __device__ __forceinline__ void mfma_rowsum(f32x4& acc, int q, const f16x8& ones
 // The accumulation registers of query block q's row sum, tied to their place (no instruction).
 template <int D>
 __device__ __forceinline__ void pin_lsum(f32x4& acc, int q) {
-  FLASH_LSUM_SWITCH(q, "", "n"(0))
+  if constexpr (kRowsumDot2) {
+    asm volatile("" : "+v"(acc));
+  } else {
+    FLASH_LSUM_SWITCH(q, "", "n"(0))
+  }
 }
 
 // Two floats to one register of packed 16-bit values of kind EK, round to nearest even
@@ -392,7 +404,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
   };
   // row sum of query block q's fragment, whose last pair was packed two elements ago
   auto group_add = [&](int q) __attribute__((always_inline)) {
-    if constexpr (!(kKnock & 16)) mfma_rowsum<D, EK>(lsum[q], q, ones_row, p_cur[q]);
+    if constexpr (!(kKnock & 16) && !kRowsumDot2) mfma_rowsum<D, EK>(lsum[q], q, ones_row, p_cur[q]);
   };
   auto finish = [&](int g) __attribute__((always_inline)) {
     const int q = g / 8, e = g % 8;
@@ -402,6 +414,11 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
       pin(w);
       p_cur[q][e - 1] = w[0];
       p_cur[q][e] = w[1];
+      if constexpr (kRowsumDot2 && EK == kF16) {
+        f16x2 one2v;
+        one2v[0] = one2v[1] = (f16)1.f;
+        lsum[q][0] = __builtin_amdgcn_fdot2(w, one2v, lsum[q][0], false);
+      }
     }
     t_exp_prev = t_exp;
   };
