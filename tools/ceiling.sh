@@ -37,6 +37,14 @@ for m in $MASKS; do
   grep -q sustained $OUT/ko$m.log || { tail $OUT/ko$m.log >&2; exit 1; }
 done | tee $OUT/knockout.log
 check ${PIPESTATUS[0]} "a knock-out pass"
+# the LDS-fragment-read knock-out in the FOUR-wave layout as well (half as many LDS instructions per launch):
+# what the reads cost there, next to its own baseline
+for m in 0 4; do
+  { FLASH_HIP_WIDE_MAX_N=0 LD_LIBRARY_PATH=gpurun_tmp/ko/$m timeout -k 10 120 tests/native/selftest bench $SHAPE 40 11 2>&1 || true; } | grep sustained | sed "s|^|[knockout4w $m] |" || exit 1
+  FLASH_HIP_WIDE_MAX_N=0 LD_LIBRARY_PATH=gpurun_tmp/ko/$m timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/ko4w$m -o p -- tests/native/selftest bench $SHAPE 5 11 > $OUT/ko4w$m.log 2>&1
+  grep -q sustained $OUT/ko4w$m.log || { tail $OUT/ko4w$m.log >&2; exit 1; }
+done | tee $OUT/knockout4w.log
+check ${PIPESTATUS[0]} "a four-wave knock-out pass"
 # the two wave layouts of the same kernel on the headline shape (FLASH_HIP_WIDE_MAX_N routes any N to the eight-wave one)
 for wide in 2048 1000000; do
   FLASH_HIP_WIDE_MAX_N=$wide timeout -k 10 120 tests/native/selftest bench $SHAPE 40 11 2>&1 | grep sustained | sed "s|^|[wide_max_n $wide] |" || exit 1

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "ceiling")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 FLOPS = 4.0 * 8 * 96 * 4096 * 4096 * 128
 
 KNOCK = {0: "nothing (the shipped kernel, eight-wave layout)", 1: "exponentials", 2: "K/V staging (global -> LDS)", 4: "LDS fragment reads",
@@ -54,6 +54,14 @@ for line in open(os.path.join(SRC, "knockout.log")):
 base = knock[0]["tflops"]
 for k in knock:
     k["speedup_vs_shipped"] = round(k["tflops"] / base, 3)
+knock4w = []
+p4 = os.path.join(SRC, "knockout4w.log")
+if os.path.exists(p4):
+    for line in open(p4):
+        m = int(re.match(r"\[knockout4w (\d+)\]", line).group(1))
+        knock4w.append(dict(mask=m, **entry(KNOCK[m].replace("eight-wave", "four-wave"), line, f"ko4w{m}")))
+    for k in knock4w:
+        k["speedup_vs_four_wave_baseline"] = round(k["tflops"] / knock4w[0]["tflops"], 3)
 layouts = []
 for line in open(os.path.join(SRC, "layouts.log")):
     n = int(re.match(r"\[wide_max_n (\d+)\]", line).group(1))
@@ -71,10 +79,17 @@ out = {
                             "not by issue slots.  (Boxes that hold their clock turn the saved cycles into time: up "
                             "to +4 % was measured for the eight-wave layout.)",
     "knockouts": knock,
+    "knockouts_four_wave_layout (FLASH_HIP_WIDE_MAX_N=0; nothing, LDS fragment reads)": knock4w,
     "knockouts_reading": "timing only, results are wrong.  Builds that freeze matrix operands (4, 8, 64, 127: stale "
                          "fragments, constant or saturated P) also lower the switching activity of the matrix pipe "
                          "itself, so they overstate what the removed work costs; 127 runs above the rate of a bare "
                          "MFMA loop on random operands for that reason.",
+    "knockouts_four_wave_reading": "the four-wave layout issues half as many LDS instructions per launch as the "
+                                   "eight-wave one, yet leaving ALL fragment reads out buys almost the same there "
+                                   "(compare speedup_vs_four_wave_baseline with mask 4 above, and the clocks): "
+                                   "what this knock-out removes is mostly not the LDS traffic but the switching "
+                                   "activity of matrix operands that no longer change, so the LDS reads themselves "
+                                   "are worth at most the difference between the two layouts' gains, a few per cent.",
     "microbench_output": open(os.path.join(SRC, "microbench.log")).read().split("\n"),
 }
 dst = os.path.join(ROOT, "profiles", f"{tag}_ceiling.json")
