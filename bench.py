@@ -337,11 +337,12 @@ def main():
                 # (profiles/traffic.json names the pass); not re-measured by this run
                 "traffic": measured_traffic(args.workload),
                 # ns: the wave layout the library picked (m16 = 4 waves x 64 query rows, m16w = 8 x 32, m16x = 4 x 128)
-                "kernel": "flash_hip::{ns}::attn_fwd_kernel_m16{}<{}, {}>".format(
+                # (third template argument: K and V are fp32 tensors converted inside the kernel; never here)
+                "kernel": "flash_hip::{ns}::attn_fwd_kernel_m16{}<{}, {}, false>".format(
                     "p" if pers else "", 128 if d > 64 else 64,
                     "_Float16" if args.dtype == "fp16" else "flash_hip::{ns}::bf16_out", ns=ns).format(ns=ns),
                 # the same kernel as rocprofv3's CSV output names it (mangled)
-                "kernel_symbol": "_ZN9flash_hip{}{}{}attn_fwd_kernel_m16{}ILi{}E{}EEvNS_9FwdParamsE".format(
+                "kernel_symbol": "_ZN9flash_hip{}{}{}attn_fwd_kernel_m16{}ILi{}E{}Lb0EEEvNS_9FwdParamsE".format(
                     len(ns), ns, 20 if pers else 19, "p" if pers else "", 128 if d > 64 else 64,
                     "DF16_" if args.dtype == "fp16" else "NS0_8bf16_outE"),
                 "kernel_ms": round(kernel_ms, 4),
