@@ -25,7 +25,14 @@ every fixture stays small.  Nothing of the reference's text is written into a fi
 repository; only numbers are.  Needs /root/reference, i.e. the build container:
 
     python tests/golden/make_golden.py           # rewrite the fixtures
-    python tests/golden/make_golden.py --check   # regenerate in memory, require bit-identical arrays
+    python tests/golden/make_golden.py --check   # regenerate in memory and compare with the files
+
+--check requires the inputs (randn draws, their fp16 roundings) and the bookkeeping arrays bit for bit.
+The outputs of the reference function and the row statistics are fp32 results of torch's CPU matmul and
+softmax, whose summation order follows the vector width of the host: on the machine that wrote the
+fixtures they reproduce bit for bit, another CPU model may differ in the last places (seen: 3.6e-7 on
+outputs of magnitude 1).  They must agree within OUT_ATOL + OUT_RTOL * |value|, a few fp32 ulps, four
+orders of magnitude below the parity bar the fixtures are used for.
 """
 import argparse
 import ast
@@ -42,6 +49,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REFERENCE_BENCH = "/root/reference/benchmarks/bench.py"
 # sha256 of ast.dump() of the reference's manual_attn definition (benchmarks/bench.py:39-43)
 MANUAL_ATTN_AST_SHA256 = "e60a531a6ae571cfec1cafba1f249a3207275a44d66ab87116fda47b1bc3a73b"
+
+# arrays computed in floating point by torch on the host, and how far another host may be off
+FLOAT_RESULTS = ("o_f32", "o", "m", "l")
+OUT_ATOL, OUT_RTOL = 1e-6, 1e-6
 
 # (B, H, N, d), heads kept
 CASES = [
@@ -120,9 +131,11 @@ def generate():
     return out
 
 
-def check():
-    """Regenerate every fixture in memory and compare with the committed files bit for bit.
-    Returns a list of differences (empty = identical)."""
+def check(notes=None):
+    """Regenerate every fixture in memory and compare with the committed files: inputs and bookkeeping bit
+    for bit, floating-point results within a few ulps (see the module docstring).  Returns a list of
+    differences (empty = the fixtures are what the reference function produces); `notes`, if given,
+    collects the arrays that agree without being bit-identical."""
     bad = []
     for name, arrays in generate().items():
         path = os.path.join(HERE, name)
@@ -135,7 +148,17 @@ def check():
                 continue
             for key, want in arrays.items():
                 got = have[key]
-                if got.dtype != want.dtype or got.shape != want.shape or got.tobytes() != want.tobytes():
+                if got.dtype != want.dtype or got.shape != want.shape:
+                    bad.append(f"{name}[{key}] differs in type or shape")
+                elif got.tobytes() == want.tobytes():
+                    continue
+                elif key in FLOAT_RESULTS and np.all(
+                        np.abs(got.astype(np.float64) - want.astype(np.float64))
+                        <= OUT_ATOL + OUT_RTOL * np.abs(want.astype(np.float64))):
+                    if notes is not None:
+                        off = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+                        notes.append(f"{name}[{key}] agrees to {off:.1e} (host-dependent last places)")
+                else:
                     bad.append(f"{name}[{key}] differs")
     return bad
 
@@ -147,10 +170,18 @@ def main():
     if not reference_available():
         sys.exit(f"{REFERENCE_BENCH} not found: fixtures are generated in the build container only")
     if args.check:
-        bad = check()
+        notes = []
+        bad = check(notes)
         for b in bad:
             print("MISMATCH", b)
-        print("golden fixtures:", "bit-identical to the reference's manual_attn run here" if not bad else "DIFFER")
+        for n in notes:
+            print("note:", n)
+        if bad:
+            print("golden fixtures: DIFFER")
+        elif notes:
+            print("golden fixtures: inputs bit-identical, results of the reference's manual_attn run here within a few ulps")
+        else:
+            print("golden fixtures: bit-identical to the reference's manual_attn run here")
         sys.exit(1 if bad else 0)
     for name, arrays in generate().items():
         path = os.path.join(HERE, name)

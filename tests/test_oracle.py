@@ -88,8 +88,9 @@ def test_bf16_rounding_matches_torch(oracle):
 
 
 def test_golden_fixtures_are_outputs_of_the_reference_function():
-    """The committed fixtures are bit-identical to what the reference's own manual_attn definition
-    (benchmarks/bench.py:39-43, executed unmodified by tests/golden/make_golden.py) produces here.
+    """The committed fixtures are what the reference's own manual_attn definition (benchmarks/bench.py:39-43,
+    executed unmodified by tests/golden/make_golden.py) produces here: inputs bit for bit, fp32 results
+    bit for bit on the CPU model that wrote them and within a few ulps (1e-6) on any other.
     Needs the reference tree, which exists in the build container only."""
     import importlib.util
     import os
