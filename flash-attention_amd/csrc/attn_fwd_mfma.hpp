@@ -241,6 +241,13 @@ __device__ __forceinline__ srd_t make_srd(const void* base, uint32_t bytes) {
 // generated code for the hazard.
 __device__ __forceinline__ void settle_scalars(srd_t& a) { asm volatile("s_nop 4" : "+s"(a)); }
 __device__ __forceinline__ void settle_scalars(srd_t& a, srd_t& b) { asm volatile("s_nop 4" : "+s"(a), "+s"(b)); }
+__device__ __forceinline__ void settle_scalars(srd_t& a, uint32_t (&o)[2]) { asm volatile("s_nop 4" : "+s"(a), "+s"(o[0]), "+s"(o[1])); }
+__device__ __forceinline__ void settle_scalars(srd_t& a, uint32_t (&o)[4]) {
+  asm volatile("s_nop 4" : "+s"(a), "+s"(o[0]), "+s"(o[1]), "+s"(o[2]), "+s"(o[3]));
+}
+__device__ __forceinline__ void settle_scalars(srd_t& a, uint32_t (&o)[8]) {
+  asm volatile("s_nop 4" : "+s"(a), "+s"(o[0]), "+s"(o[1]), "+s"(o[2]), "+s"(o[3]), "+s"(o[4]), "+s"(o[5]), "+s"(o[6]), "+s"(o[7]));
+}
 __device__ __forceinline__ void settle_scalars(srd_t& a, srd_t& b, uint32_t& c, uint32_t& d) {
   asm volatile("s_nop 4" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
 }

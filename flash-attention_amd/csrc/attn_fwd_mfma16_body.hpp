@@ -46,6 +46,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FLASH_KNOCKOUT 0
 #endif
 constexpr int kKnock = FLASH_KNOCKOUT;
+#ifndef FLASH_TRACK_MODE
+#define FLASH_TRACK_MODE 1
+#endif
+constexpr int kTrackMode = FLASH_TRACK_MODE;
 // Comparison builds (-DFLASH_ROWSUM_DOT2): in the eight-wave layout the row sums are taken on the vector ALU
 // (v_dot2_f32_f16 of every packed pair of probabilities with ones, fp32 accumulation, one partial sum per
 // lane) instead of on the matrix pipe.
@@ -371,7 +375,8 @@ __device__ __forceinline__ void mask_tile(f32x4& s, int kv_tile0, int N, int lan
 // One pipeline step: QK(j+1) (32 MFMAs), PV(j-1) (32 MFMAs), exp(j), in-lane max(j+1).
 //   s_cur/s_nxt[kb][q]: S^T tiles of key block kb (16 keys) and query block q (16 queries)
 //   p_prev/p_cur[q]:    P^T fragments (32 keys) of query block q
-template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, int PV_MODE = kPvAccumulate, int EK = kF16, typename Hook>
+template <int D, bool HAS_QK, bool HAS_PRELOAD, bool MASKED, int PV_MODE = kPvAccumulate, int EK = kF16, bool TRACK = true,
+          typename Hook>
 __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off, uint32_t vb_off, uint32_t kb_next_off,
                                               const LaneAddr<D>& la, const f32x4 (&bias)[kQ16],
                                               const f16x8 (&qf)[kQ16][Cfg<D>::kKS], f16x8 (&ka)[4],
@@ -519,7 +524,7 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
       if (PV_MODE != kPvSkip && !(kKnock & 4) && q == kQ16 - 1 && b + 4 < kDv16) va[b % 4] = read_v<D>(vb_off, la, b + 4);
       exp_share(QK_SLOTS + pslot);
       if constexpr (!(kKnock & 2)) hook(QK_SLOTS + pslot);
-      if constexpr (HAS_QK) {
+      if constexpr (HAS_QK && TRACK) {
 #pragma unroll
         for (int u = 0; u < MAX_OPS; ++u) {
           if (MAX_DELAY + u * (PV_SLOTS - MAX_DELAY) / MAX_OPS == pslot) max_op(u);
@@ -534,14 +539,14 @@ __device__ __forceinline__ void pipeline_step(const Hook& hook, uint32_t kb_off,
   // exceeds the deferral threshold) joined with the pending-rescale mask by one scalar OR.  Written
   // out: from `pending || ballot(...)` the compiler builds the same condition out of five scalar
   // instructions, and at one wave per SIMD every instruction is issue time.
-  if constexpr (HAS_QK) {
+  if constexpr (HAS_QK && TRACK) {
     asm volatile("v_cmp_lt_f32 vcc, %1, %2\n\ts_or_b64 %0, vcc, %3"
                  : "=s"(vote)
                  : "s"(sc.thr), "v"(mx_all), "s"(pending)
                  : "vcc", "scc", "memory");
   } else {
     vote = pending;
-    asm volatile("s_nop 1" ::: "memory");
+    asm volatile("s_nop 1" : "+s"(vote) : : "memory");
   }
   group_add(kQ16 - 1);
 }
@@ -569,11 +574,26 @@ __device__ __forceinline__ void bias_ready(f32x4 (&bias)[kQ16]) {
 }
 
 // Between two steps: pending O rescale, then the decision whether the next block moves a reference.
-template <int NB, bool HAS_NEXT>
+// The score tiles and the bias registers, named at a point of the program without an instruction (for the
+// register allocator only: at this point they sit in vector registers, whole).
+__device__ __forceinline__ void pin_tiles(f32x4 (&s)[2][kQ16], f32x4 (&bias)[kQ16]) {
+#pragma unroll
+  for (int q = 0; q < kQ16; ++q) asm volatile("" : "+v"(s[0][q]), "+v"(s[1][q]), "+v"(bias[q]));
+}
+
+// Steps that do not take the running maximum leave `mx_all` alone: it must then hold a value that moves no
+// reference (the compiler cannot see which value it holds, and keeps the rare path of every step).
+__device__ __forceinline__ void forget_max(float& mx_all) {
+  mx_all = -INFINITY;
+  asm volatile("" : "+v"(mx_all));
+}
+
+template <int NB, bool HAS_NEXT, bool PIN = false>
 __device__ __forceinline__ void step_end(f32x4 (&o)[kQ16][NB], State (&st)[kQ16], const float mx_all,
                                          f32x4 (&lsum)[kQ16], f32x4 (&bias)[kQ16], f32x4 (&s_nxt)[2][kQ16],
                                          uint64_t& pending, const uint64_t vote, const ScaleSplit sc, int lane) {
   // `vote` = pending-rescale mask | lanes whose next-block maximum exceeds the threshold (pipeline_step)
+  if constexpr (PIN) pin_tiles(s_nxt, bias);
   if (__builtin_expect(vote != 0, 0)) {
     bool any_need = false;
     if constexpr (HAS_NEXT) any_need = __builtin_amdgcn_ballot_w64(mx_all > sc.thr) != 0;
@@ -1032,8 +1052,10 @@ struct CfgP : Cfg<D> {
 
 // 16 bytes per lane from a raw buffer straight into accumulation registers.  Not tracked by the
 // compiler: the caller waits (s_waitcnt vmcnt) before the registers are used.
-__device__ __forceinline__ void load_q_raw(f16x8& dst, srd_t srd, uint32_t voff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=a"(dst) : "v"(voff), "s"(srd) : "memory");
+// `soff` is a wave-uniform byte offset that the range check does not see (it checks `voff`): the caller knows
+// that voff + soff stays inside the buffer whenever voff does.
+__device__ __forceinline__ void load_q_raw(f16x8& dst, srd_t srd, uint32_t voff, uint32_t soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
 }
 
 // Wait for the Q loads: all vector memory operations but the YOUNGER most recent ones.  The registers
@@ -1054,6 +1076,9 @@ __device__ __forceinline__ void wait_q(f16x8 (&qf)[kQ16][KS]) {
   }
 }
 
+constexpr int kOverflowWords = 32;  // 1024 item ordinals; a workgroup with more items shares bits (a set bit
+                                    // then repeats every item that maps to it, which only costs time)
+
 // KV32: as in attn_fwd_kernel_m16, K and V are the caller's fp32 tensors and every wave converts its share
 // of a tile on its way into LDS (TO = float, four-wave layout).
 template <int D, typename TO = f16, bool KV32 = false>
@@ -1065,6 +1090,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   constexpr int kPiecesPerWave = C::kPiecesPerWave;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_char* const smem = (lds_char*)smem_raw;
+  // one bit per work item of this workgroup (ordinal modulo the size): set when the item's first pass overflowed
+  __shared__ uint32_t overflowed[kOverflowWords];
   FLASH_STAMP(stamp_entry);
 
   // Items are dealt to the 8 XCDs in contiguous ranges (workgroup ids equal mod 8 share an XCD);
@@ -1076,8 +1103,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const uint32_t per = p.total_wg >> 3, rem = p.total_wg & 7u;
   const uint32_t lo = xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
   const uint32_t hi = lo + per + (xcd < rem ? 1u : 0u);
-  uint32_t item = lo + slot_id;
-  if (item >= hi) return;
+  const uint32_t first_item = lo + slot_id;
+  if (first_item >= hi) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1087,6 +1114,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const int N = p.N, d = p.d;
   const ScaleSplit sc{p.s_scale, p.defer_thr};
   const int nt = N / kBc;  // multiple of 4
+  if (tid < kOverflowWords) overflowed[tid] = 0u;  // published by the barrier that ends the cold start
+  uint32_t ordinal = 0;                            // of the current item among this workgroup's items
 
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
@@ -1179,31 +1208,33 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   // measured 1 % slower with it, the eight-wave layout the same with and without.
   constexpr int kOutAux = (D == 128 && kQ16 == 4) ? 19 : 0;
 
-  // per-lane byte offsets of the Q chunks inside a head, for query tile 0 (a tile adds kBr rows)
-  uint32_t q_off[kQ16][kKS];
+  // per-lane byte offsets of the Q chunks inside a head, for query block 0 of query tile 0: the tile (kBr
+  // rows) and the query block (16 rows) are a wave-uniform offset that the loads take from a scalar
+  // register (whole tiles only: every row exists, so only the chunk, per lane, needs the range check; a
+  // chunk beyond d stays out of range through its per-lane part).  One register per k-step lives through
+  // the kernel instead of one per k-step and query block.
+  uint32_t q_off[kKS];
 #pragma unroll
-  for (int q = 0; q < kQ16; ++q) {
-#pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) {
-      const int col = 8 * (ks + kKS * g);
-      const uint32_t row = (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
-      q_off[q][ks] = (col < d) ? (row * (uint32_t)d + (uint32_t)col) * kQElem : kOob;
-    }
+  for (int ks = 0; ks < kKS; ++ks) {
+    const int col = 8 * (ks + kKS * g);
+    const uint32_t row = (uint32_t)(wave * kRowsPerWave + n16);
+    q_off[ks] = (col < d) ? (row * (uint32_t)d + (uint32_t)col) * kQElem : kOob;
   }
   const uint32_t q_tile_bytes = (uint32_t)kBr * (uint32_t)d * kQElem;
+  const uint32_t q_block_bytes = 16u * (uint32_t)d * kQElem;
 
   f16x8 qf[kQ16][kKS];
   auto fetch_q = [&](uint32_t it) __attribute__((always_inline)) {
     const uint32_t hd = head_of(it), qt = it - hd * (uint32_t)p.nqt;
     srd_t q_srd = make_srd((const f16*)p.q + (size_t)hd * head_elems, head_bytes);
-    settle_scalars(q_srd);
+    uint32_t soff[kQ16];
+#pragma unroll
+    for (int q = 0; q < kQ16; ++q) soff[q] = __builtin_amdgcn_readfirstlane(qt * q_tile_bytes + (uint32_t)q * q_block_bytes);
+    settle_scalars(q_srd, soff);
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
 #pragma unroll
-      for (int ks = 0; ks < kKS; ++ks) {
-        // a chunk beyond d keeps its out-of-range offset: adding the tile offset cannot wrap below kOob
-        load_q_raw(qf[q][ks], q_srd, q_off[q][ks] + qt * q_tile_bytes);
-      }
+      for (int ks = 0; ks < kKS; ++ks) load_q_raw(qf[q][ks], q_srd, q_off[ks], soff[q]);
     }
   };
 
@@ -1234,12 +1265,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
             // row exists; a chunk beyond d stays out of range through its per-lane part)
             const uint32_t soff = __builtin_amdgcn_readfirstlane(
                 qt * q_tile_bytes + (uint32_t)((ph * kQPerPhase + q) * 16) * (uint32_t)d * kQElem);
-            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[0][ks], soff, 0);
-            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[0][ks] + 16u, soff, 0);
+            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
+            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks] + 16u, soff, 0);
           } else {
-            const uint32_t off = q_off[ph * kQPerPhase + q][ks] + qt * q_tile_bytes;
-            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off, 0, 0);
-            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, off + 16u, 0, 0);
+            const uint32_t soff = __builtin_amdgcn_readfirstlane(
+                qt * q_tile_bytes + (uint32_t)(ph * kQPerPhase + q) * q_block_bytes);
+            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
+            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks] + 16u, soff, 0);
           }
         }
       }
@@ -1259,6 +1291,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
   };
 
+  // A sweep over work items: `start_item` from a cold start, then (chain) every wgs_on_xcd-th item after it
+  // with the staging running across the item boundaries.  SPARSE: only a few steps of an item take the
+  // running maximum (see below); an item whose probabilities left the fp16 range on the way is marked in
+  // `overflowed` and its output is not valid.
+  auto sweep = [&](auto sparse_tag, const uint32_t start_item, const bool chain) __attribute__((always_inline)) {
+  constexpr bool SPARSE = decltype(sparse_tag)::value;
+  uint32_t item = start_item;
   // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
   srd_t k_srd = kv_srd(p.k, head_of(item)), v_srd = kv_srd(p.v, head_of(item));
   settle_scalars(k_srd, v_srd);
@@ -1331,6 +1370,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   f16x8 ka[4];
   State st[kQ16];
   float mx_all = 0.f;  // in-lane maximum of the block whose scores were computed last
+  forget_max(mx_all);
   uint64_t vote = 0;   // see pipeline_step / step_end
   f32x4 bias[kQ16];
   f32x4 lsum[kQ16];
@@ -1342,7 +1382,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   for (;;) {
     FLASH_STAMP(stamp_item);
     const uint32_t next_item = item + wgs_on_xcd;
-    const bool has_next = next_item < hi;
+    const bool has_next = chain && next_item < hi;
     const uint32_t next_head = has_next ? head_of(next_item) : head_of(item);
     const uint32_t head = head_of(item), qt = item - head * (uint32_t)p.nqt;
     TO* oh = (TO*)p.o + (size_t)head * head_elems;
@@ -1394,8 +1434,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     FLASH_STAMP(stamp_loop);
     // CROSS marks the last two tile iterations of an item, whose staging targets (K tile t+2, V tile
     // t+1) may already be the first tiles of the next item; all others stage from the current head.
-    auto tile_iter = [&](auto slot_tag, auto cross_tag, auto last_tag, auto first_tag, int t) __attribute__((always_inline)) {
+    auto tile_iter = [&](auto slot_tag, auto cross_tag, auto last_tag, auto first_tag, auto track_tag, int t) __attribute__((always_inline)) {
       constexpr int S0 = decltype(slot_tag)::value;
+      // which of the tile's two steps take the running maximum of the block they compute (bit 0: first step)
+      constexpr bool TRACK1 = (decltype(track_tag)::value & 1) != 0, TRACK2 = (decltype(track_tag)::value & 2) != 0;
       constexpr bool CROSS = decltype(cross_tag)::value;
       constexpr bool LAST = decltype(last_tag)::value;
       // tile 0 of an item: its first step has no P to multiply yet, its second step starts O
@@ -1456,9 +1498,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       };
       constexpr uint32_t k_cur = (uint32_t)(S0 * kTileBytes), k_nxt = (uint32_t)(S1 * kTileBytes);
       constexpr uint32_t v_cur = (uint32_t)(S0 * kTileBytes), v_prv = (uint32_t)(S3 * kTileBytes);
-      pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate, EK>(
+      pipeline_step<D, true, !LAST, false, FIRST ? kPvSkip : kPvAccumulate, EK, TRACK1>(
           hook1, k_cur + kBlkBytes, v_prv + kBlkBytes, k_nxt, la, bias, qf, ka, o, sA, sB, pB, pA, mx_all, lsum, sc, pending, vote, 0, N, lane);
       step_end<kDv16, true>(o, st, mx_all, lsum, bias, sB, pending, vote, sc, lane);
+      if constexpr (TRACK1 && !TRACK2) forget_max(mx_all);
       if constexpr (LAST) {
         // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
         // loads have the last step, the last P V product and the output stores to land.
@@ -1468,9 +1511,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
           if (has_next) fetch_q(next_item);
         }
       }
-      pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate, EK>(
+      pipeline_step<D, !LAST, !LAST, false, FIRST ? kPvFirst : kPvAccumulate, EK, TRACK2>(
           hook2, k_nxt, v_cur, k_nxt + kBlkBytes, la, bias, qf, ka, o, sB, sA, pA, pB, mx_all, lsum, sc, pending, vote, 0, N, lane);
       step_end<kDv16, !LAST>(o, st, mx_all, lsum, bias, sA, pending, vote, sc, lane);
+      if constexpr (TRACK2 && SPARSE) forget_max(mx_all);
       if constexpr (LAST) {
         // wait for this wave's staging pieces, which are older than the Q loads, but not for those
         if (has_next && !QF32) {
@@ -1486,16 +1530,27 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     using std::integral_constant;
     constexpr std::true_type yes{};
     constexpr std::false_type no{};
-    tile_iter(integral_constant<int, 0>{}, no, no, yes, 0);
-    tile_iter(integral_constant<int, 1>{}, no, no, no, 1);
+    // Steps that take the running maximum (kTrackMode): every step, or tile 0 and the first step of every
+    // fourth tile after it, or none.
+#ifndef FLASH_TRACK_FIRST
+#define FLASH_TRACK_FIRST 3
+#endif
+#ifndef FLASH_TRACK_LOOP
+#define FLASH_TRACK_LOOP 2
+#endif
+    constexpr integral_constant<int, !SPARSE ? 3 : (kTrackMode == 1 ? FLASH_TRACK_FIRST : 0)> trk_first{};
+    constexpr integral_constant<int, !SPARSE ? 3 : (kTrackMode == 1 ? FLASH_TRACK_LOOP : 0)> trk_loop{};
+    constexpr integral_constant<int, !SPARSE ? 3 : 0> trk_rest{};
+    tile_iter(integral_constant<int, 0>{}, no, no, yes, trk_first, 0);
+    tile_iter(integral_constant<int, 1>{}, no, no, no, trk_rest, 1);
     for (int t = 2; t + 2 < nt; t += 4) {
-      tile_iter(integral_constant<int, 2>{}, no, no, no, t);
-      tile_iter(integral_constant<int, 3>{}, no, no, no, t + 1);
-      tile_iter(integral_constant<int, 0>{}, no, no, no, t + 2);
-      tile_iter(integral_constant<int, 1>{}, no, no, no, t + 3);
+      tile_iter(integral_constant<int, 2>{}, no, no, no, trk_loop, t);
+      tile_iter(integral_constant<int, 3>{}, no, no, no, trk_rest, t + 1);
+      tile_iter(integral_constant<int, 0>{}, no, no, no, trk_rest, t + 2);
+      tile_iter(integral_constant<int, 1>{}, no, no, no, trk_rest, t + 3);
     }
-    tile_iter(integral_constant<int, 2>{}, yes, no, no, nt - 2);
-    tile_iter(integral_constant<int, 3>{}, yes, yes, no, nt - 1);
+    tile_iter(integral_constant<int, 2>{}, yes, no, no, trk_rest, nt - 2);
+    tile_iter(integral_constant<int, 3>{}, yes, yes, no, trk_rest, nt - 1);
 
     FLASH_STAMP(stamp_tail);
 
@@ -1522,6 +1577,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         if constexpr (kQPhases > 1) fetch_q32(next_item, 1);
       }
     }
+    uint32_t worst = 0u;  // largest row sum of the wave as an integer: infinities and NaNs compare above every number
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
       if constexpr (QF32 && !kQEarly) {
@@ -1531,9 +1587,24 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
           if (has_next) fetch_q32(next_item, q / kQPerPhase);
         }
       }
-      const float inv = __builtin_amdgcn_rcpf(quad_lane_sum(lsum[q][0], lane));  // v_rcp_f32, 1 ulp
+      const float l = quad_lane_sum(lsum[q][0], lane);
+      if constexpr (SPARSE) {
+        const uint32_t lbits = __float_as_uint(l) & 0x7fffffffu;
+        worst = worst > lbits ? worst : lbits;
+      }
+      const float inv = __builtin_amdgcn_rcpf(l);  // v_rcp_f32, 1 ulp
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
       store_o_block<kDv16, TO, kOutAux>(o[q], inv, qrow, d, g, o_rs);
+    }
+    if constexpr (SPARSE) {
+      // A probability beyond the fp16 range (a score more than 16 exp2 units above a reference that most
+      // steps no longer update) shows as an infinite row sum: the item is marked and computed again below.
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst >= 0x7f800000u) != 0, 0)) {
+        if (lane == 0) {
+          __hip_atomic_fetch_or(&overflowed[(ordinal >> 5) % kOverflowWords], 1u << (ordinal & 31u), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
     }
 #if defined(FLASH_PHASE_STAMPS)
     if (!has_next) {
@@ -1564,8 +1635,36 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     ++n_items;
 #endif
     item = next_item;
+    ++ordinal;
     k_srd = kv_srd(p.k, next_head);
     v_srd = kv_srd(p.v, next_head);
+  }
+  };  // sweep
+
+  // (The d = 128 kernel that converts fp32 K and V itself has no register to spare for the few values the
+  // second pass keeps across the first: it takes the maximum in every step, in one pass.)
+  if constexpr (kTrackMode == 0 || (KV32 && D == 128)) {
+    sweep(std::false_type{}, first_item, true);
+  } else {
+    sweep(std::true_type{}, first_item, true);
+    // ---- second pass: the items whose first pass overflowed, one at a time from a cold start, with the
+    // running maximum taken in every step (no input makes that pass overflow).  Their output rows are
+    // written again by the waves that wrote them first, after those stores have completed.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t any = 0u;
+#pragma unroll
+    for (int w = 0; w < kOverflowWords; ++w) any |= overflowed[w];
+    if (__builtin_expect(__builtin_amdgcn_readfirstlane(any) != 0u, 0)) {
+      uint32_t ord = 0;
+#pragma unroll 1
+      for (uint32_t it = first_item; it < hi; it += wgs_on_xcd, ++ord) {
+        const uint32_t word = __builtin_amdgcn_readfirstlane(overflowed[(ord >> 5) % kOverflowWords]);
+        if (((word >> (ord & 31u)) & 1u) == 0u) continue;
+        __syncthreads();  // the last V fragments of the item before have been read
+        sweep(std::false_type{}, it, false);
+      }
+    }
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }

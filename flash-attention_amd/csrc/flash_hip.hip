@@ -148,12 +148,15 @@ int current_device(int* dev) {
 
 // Workgroups of the persistent kernel on device `dev`: one per CU (the kernel needs a CU's whole
 // register file and most of its LDS), never more than there are items.
+int64_t grid_limit();  // FLASH_HIP_GRID (below, with the other switches)
 uint32_t persistent_grid(uint32_t items, int dev) {
   int n = (dev >= 0 && dev < kMaxDevices) ? g_cu_count[dev].load(std::memory_order_relaxed) : 0;
   if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     if (dev >= 0 && dev < kMaxDevices) g_cu_count[dev].store(n, std::memory_order_relaxed);
   }
+  const int64_t limit = grid_limit();
+  if (limit > 0 && limit < n) n = (int)limit;
   const uint32_t g = (uint32_t)n & ~7u;  // a multiple of the 8 XCDs
   return items < g ? items : (g ? g : 8u);
 }
@@ -252,6 +255,8 @@ constexpr int64_t kVecDefaultMaxN64 = 768;
 //   FLASH_HIP_TALL=0               keep head dims up to 64 on 256-row query tiles
 //   FLASH_HIP_VEC_MAX_N=<n>        longest sequence on which fp32 callers with a workspace still take the
 //                                  register-staged kernel instead of the conversion pass (0 = never)
+//   FLASH_HIP_GRID=<n>             at most n persistent workgroups (a multiple of 8; default: one per CU):
+//                                  long item chains per workgroup on small inputs, for tests
 // They are read once per process, on the first call that routes anything, and again only when
 // flash_hip_reload_switches() is called: the hot path does no environment lookups, and a warmed-up HIP graph
 // capture stays on the kernels it was warmed up with.
@@ -261,6 +266,7 @@ struct Switches {
   int64_t wide_max_n;
   bool tall;
   int64_t vec_max_n;  // < 0: the per-head-dim defaults
+  int64_t grid;       // <= 0: one persistent workgroup per CU
 };
 Switches read_switches() {
   auto flag = [](const char* name) {
@@ -277,6 +283,7 @@ Switches read_switches() {
   s.wide_max_n = num("FLASH_HIP_WIDE_MAX_N", (int64_t)1 << 40);
   s.tall = flag("FLASH_HIP_TALL");
   s.vec_max_n = num("FLASH_HIP_VEC_MAX_N", -1);
+  s.grid = num("FLASH_HIP_GRID", 0);
   return s;
 }
 // The current set: published through one pointer, so a reload is safe against calls in flight on other
@@ -292,6 +299,7 @@ Switches switches() {
   if (!s) s = publish_switches();  // racing first calls read the same environment
   return *s;
 }
+int64_t grid_limit() { return switches().grid; }
 
 // Whole-tile d = 128 shapes run the persistent kernel in the eight-wave layout (two waves per SIMD, 32
 // query rows each).  The two waves of a SIMD fill each other's matrix-pipe gaps: at the item boundaries,
