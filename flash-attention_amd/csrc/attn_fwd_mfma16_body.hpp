@@ -1128,6 +1128,20 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   lds_char* const k_ring = smem;
   lds_char* const v_ring = smem + kRingP * kTileBytes;
 
+  // A sweep over work items: `start_item` from a cold start, then (chain) every wgs_on_xcd-th item after it
+  // with the staging running across the item boundaries.  SPARSE: only a few steps of an item take the
+  // running maximum (see below); an item whose probabilities left the fp16 range on the way is marked in
+  // `overflowed` and its output is not valid.
+  // Everything a lane keeps for a whole sweep (LDS and buffer offsets of its fragments, pieces and Q chunks)
+  // is worked out inside, from a lane number the compiler cannot recognise as the same in both sweeps of the
+  // kernel: the two then share no vector register, and neither constrains the other's allocation.
+  auto sweep = [&](auto sparse_tag, const uint32_t start_item, const bool chain) __attribute__((always_inline)) {
+  constexpr bool SPARSE = decltype(sparse_tag)::value;
+  // (the lane's number inside its wave, counted by the hardware: no register carries it from sweep to sweep)
+  int lane_opaque = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane_opaque));
+  const int lane = lane_opaque, n16 = lane & 15, g = lane >> 4;
+
   uint32_t dma_off[kPiecesPerWave];
 #pragma unroll
   for (int i = 0; i < kPiecesPerWave; ++i) {
@@ -1265,13 +1279,15 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
             // row exists; a chunk beyond d stays out of range through its per-lane part)
             const uint32_t soff = __builtin_amdgcn_readfirstlane(
                 qt * q_tile_bytes + (uint32_t)((ph * kQPerPhase + q) * 16) * (uint32_t)d * kQElem);
+            // (the chunk's second half through the scalar offset as well: a per-lane `q_off + 16` would be one
+            // more register per k-step that lives through the kernel)
             q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
-            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks] + 16u, soff, 0);
+            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff + 16u, 0);
           } else {
             const uint32_t soff = __builtin_amdgcn_readfirstlane(
                 qt * q_tile_bytes + (uint32_t)(ph * kQPerPhase + q) * q_block_bytes);
             q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
-            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks] + 16u, soff, 0);
+            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff + 16u, 0);
           }
         }
       }
@@ -1291,12 +1307,6 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
   };
 
-  // A sweep over work items: `start_item` from a cold start, then (chain) every wgs_on_xcd-th item after it
-  // with the staging running across the item boundaries.  SPARSE: only a few steps of an item take the
-  // running maximum (see below); an item whose probabilities left the fp16 range on the way is marked in
-  // `overflowed` and its output is not valid.
-  auto sweep = [&](auto sparse_tag, const uint32_t start_item, const bool chain) __attribute__((always_inline)) {
-  constexpr bool SPARSE = decltype(sparse_tag)::value;
   uint32_t item = start_item;
   // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
   srd_t k_srd = kv_srd(p.k, head_of(item)), v_srd = kv_srd(p.v, head_of(item));
@@ -1641,9 +1651,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   }
   };  // sweep
 
-  // (The d = 128 kernel that converts fp32 K and V itself has no register to spare for the few values the
-  // second pass keeps across the first: it takes the maximum in every step, in one pass.)
-  if constexpr (kTrackMode == 0 || (KV32 && D == 128)) {
+  if constexpr (kTrackMode == 0) {
     sweep(std::false_type{}, first_item, true);
   } else {
     sweep(std::true_type{}, first_item, true);
@@ -1653,8 +1661,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t any = 0u;
+    // (timing-only knock-out builds compute garbage on purpose: their items are not repeated)
 #pragma unroll
-    for (int w = 0; w < kOverflowWords; ++w) any |= overflowed[w];
+    for (int w = 0; w < kOverflowWords; ++w) any |= kKnock == 0 ? overflowed[w] : 0u;
     if (__builtin_expect(__builtin_amdgcn_readfirstlane(any) != 0u, 0)) {
       uint32_t ord = 0;
 #pragma unroll 1

@@ -20,7 +20,7 @@ if [ "$1" = build ]; then
       flash-attention_amd/csrc/flash_hip.hip -o gpurun_tmp/ko/$m/libflash_hip.so 2>/dev/null &
     while [ "$(jobs -r | wc -l)" -ge 4 ]; do sleep 1; done
   done
-  for f in mfma_clock issue_cost lds_issue_cost; do
+  for f in mfma_clock issue_cost lds_issue_cost softmax_issue_cost; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/microbench/$f.cpp -o gpurun_tmp/mb/$f 2>/dev/null &
   done
   wait
@@ -51,7 +51,7 @@ for wide in 2048 1000000; do
   FLASH_HIP_WIDE_MAX_N=$wide timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT/wide$wide -o p -- tests/native/selftest bench $SHAPE 5 11 > $OUT/wide$wide.log 2>&1 || { tail $OUT/wide$wide.log; exit 1; }
 done | tee $OUT/layouts.log
 check ${PIPESTATUS[0]} "a wave-layout pass"
-for f in mfma_clock issue_cost lds_issue_cost; do
+for f in mfma_clock issue_cost lds_issue_cost softmax_issue_cost; do
   echo "== $f"
   timeout -k 10 200 gpurun_tmp/mb/$f 2>&1 || exit 1
 done | tee $OUT/microbench.log
