@@ -63,7 +63,8 @@ typedef struct flash_launch_info {
   uint32_t tile_kv;      /* Bc: K/V rows per LDS tile                (tileSize().x) */
   uint32_t tile_q;       /* Br: Q rows per workgroup: 256, or 512 for head dims <= 64 with N % 512 == 0 (tileSize().y) */
   uint32_t tile_d;       /* head dim padded to the compiled tile     (tileSize().z) */
-  uint32_t lds_bytes;    /* dynamic LDS per workgroup                (sramSize())   */
+  uint32_t lds_bytes;    /* dynamic LDS per workgroup                (sramSize()); persistent kernels hold
+                            128 bytes of static LDS besides (their overflow marks, see `persistent`) */
   uint32_t block_x;      /* lanes per wave = 64                      (blockDim().x) */
   uint32_t block_y;      /* waves per workgroup: 4, or 8 for whole-tile shapes with d > 64 (blockDim().y) */
   uint32_t grid_x;       /* B                                        (gridDim().x)  */
@@ -77,7 +78,13 @@ typedef struct flash_launch_info {
   uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */
   uint32_t persistent;   /* 1: the work items (grid_x * grid_y * grid_z of them) are walked by a persistent
                             kernel launched as a 1-D grid of min(items, compute units rounded down to a
-                            multiple of 8) workgroups; 0: one workgroup per item, 1-D grid of all items */
+                            multiple of 8) workgroups; 0: one workgroup per item, 1-D grid of all items.
+                            A persistent kernel takes the softmax's running maximum in a few steps of an item
+                            only; an item in which a probability left the fp16 range on the way (a score more
+                            than 16 exp2 units above everything those steps saw) is computed a second time by
+                            the same workgroup, with the maximum in every step, before the kernel ends.  The
+                            result is the same either way; the time of a call therefore depends on its data
+                            (up to about twice on inputs built so that every item overflows). */
 } flash_launch_info;
 
 /* Which entry point a geometry query describes. */
