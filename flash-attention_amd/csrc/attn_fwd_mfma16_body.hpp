@@ -41,7 +41,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Timing-only diagnostic builds (-DFLASH_KNOCKOUT=<mask>, results are wrong): leave one kind of
 // per-step work out of the pipeline steps to see what it costs.  1 exponentials, 2 K/V staging,
 // 4 LDS fragment reads, 8 conversions of P to 16 bit, 16 row sums, 32 running maximum, 64 the score
-// multiply.  tools/ceiling.sh builds and times them.
+// multiply, 128 the output path (scaling, conversion and stores of O).  tools/ceiling.sh builds and times
+// the first seven.
 #ifndef FLASH_KNOCKOUT
 #define FLASH_KNOCKOUT 0
 #endif
@@ -358,6 +359,24 @@ __device__ __forceinline__ f16x8 read_v(uint32_t voff, const LaneAddr<D>& la, in
   return a;
 }
 
+// Eight consecutive fp32 values of a buffer (32 bytes at byte offset `voff`, range-checked) as eight fp16
+// values in two register pairs: a typed buffer load with a 16-bit destination lets the memory pipeline
+// convert (32_32_32_32 FLOAT data, four values per instruction).  It rounds to nearest even like
+// v_cvt_pk_f16_f32 (tools/microbench/d16_load.cpp compares them value by value, ties and subnormals
+// included); finite values beyond the fp16 range arrive as +-65504 where the instruction gives +-inf, NaN
+// stays NaN, out-of-range addresses read as zeros.  It streams at the rate of a plain 128-bit load.
+// Issued from inline asm (the compiler has no builtin for it) and therefore not tracked: the caller waits
+// with s_waitcnt vmcnt before it uses the registers.
+__device__ __forceinline__ void load_kv_f32_as_f16(u32x2& lo, u32x2& hi, srd_t srd, uint32_t voff) {
+  asm volatile(
+      "s_nop 4\n\t"
+      "tbuffer_load_format_d16_xyzw %0, %2, %3, 0 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen\n\t"
+      "tbuffer_load_format_d16_xyzw %1, %2, %3, 0 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen offset:16"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(voff), "s"(srd)
+      : "memory");
+}
+
 struct State {
   float mc;       // reference of the lane's query in this query block, in accumulator units (exp2 units / s_scale)
   float alpha;    // pending O factor
@@ -669,6 +688,7 @@ constexpr int kElemKindOf = std::is_same<TO, bf16_out>::value ? kBF16 : kF16;
 template <int NB, typename TO, int AUX = 0>
 __device__ __forceinline__ void store_o_block(const f32x4 (&oq)[NB], float inv, uint32_t qrow, int d, int g,
                                               __amdgpu_buffer_rsrc_t o_rs) {
+  if constexpr ((kKnock & 128) != 0) return;  // timing only: what scaling, converting and storing O costs
   if constexpr (sizeof(TO) == 2) {
 #pragma unroll
     for (int b = 0; b < NB; b += 2) {
@@ -791,21 +811,27 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + slot * kTileBytes + pc * 1024));
     dma_piece(srd, dma_off[i] + (uint32_t)t * tile_step, lds_base);
   };
-  // fp32 K/V: the two halves of piece i's chunk land in registers (the compiler tracks these loads and
-  // waits for them where they are converted), ...
-  const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc((void*)kh, 0, head_bytes * (kKVElem / 2u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc((void*)vh, 0, head_bytes * (kKVElem / 2u), 0x00020000);
-  u32x4 land[KV32 ? kPiecesPerWave : 1][2];
-  auto load_piece = [&](const __amdgpu_buffer_rsrc_t rs, int t, int i) __attribute__((always_inline)) {
-    // (an out-of-range chunk keeps an out-of-range offset: kOob plus a tile offset stays below 2^31)
-    const uint32_t off = dma_off[i] + (uint32_t)t * tile_step;
-    land[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-    land[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16u, 0, 0);
+  // fp32 K/V: the memory pipeline converts (typed loads with a 16-bit destination, see load_kv_f32_as_f16):
+  // the two halves of piece i's chunk arrive as fp16 in two register pairs ...
+  u32x2 land[KV32 ? kPiecesPerWave : 1][2];
+  auto load_piece = [&](const srd_t srd, int t, int i) __attribute__((always_inline)) {
+    // (the tile offset is part of the per-lane offset here, so that rows beyond N fail the range check and
+    // read as zeros; an out-of-range chunk keeps an out-of-range offset: kOob plus a tile offset stays
+    // below 2^31)
+    load_kv_f32_as_f16(land[i][0], land[i][1], srd, dma_off[i] + (uint32_t)t * tile_step);
   };
-  // ... and are written, rounded to fp16, to the place the DMA would have filled
+  // ... and are written to the place the DMA would have filled.  The compiler does not see these loads:
+  // the wait counts the younger loads of the same tile (vector memory loads complete in order).
   const uint32_t lds_lane = (uint32_t)(wave * kPiecesPerWave * 1024 + lane * 16);
   auto write_piece = [&](lds_char* ring, int slot, int i) __attribute__((always_inline)) {
-    *FLASH_LDS_CAST(f16x8, ring + slot * kTileBytes + i * 1024 + lds_lane) = q_frag_from_f32(land[i][0], land[i][1]);
+    switch (2 * (kPiecesPerWave - 1 - i)) {  // (an immediate operand)
+      case 0: asm volatile("s_waitcnt vmcnt(0)" : "+v"(land[i][0]), "+v"(land[i][1]) : : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" : "+v"(land[i][0]), "+v"(land[i][1]) : : "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" : "+v"(land[i][0]), "+v"(land[i][1]) : : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(6)" : "+v"(land[i][0]), "+v"(land[i][1]) : : "memory"); break;
+    }
+    *FLASH_LDS_CAST(u32x4, ring + slot * kTileBytes + i * 1024 + lds_lane) =
+        u32x4{land[i][0][0], land[i][0][1], land[i][1][0], land[i][1][1]};
   };
   auto stage = [&](const srd_t srd, lds_char* ring, int slot, int t) __attribute__((always_inline)) {
 #pragma unroll
@@ -841,22 +867,21 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
     // all three tiles' loads in flight at once (the score and probability registers are still free):
     // one memory round trip for the cold start instead of three.  Tile 1 of a one-tile sequence lies
     // beyond the head: its loads return zeros.
-    u32x4 cold[3][kPiecesPerWave][2];
+    u32x2 cold[3][kPiecesPerWave][2];
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
 #pragma unroll
       for (int i = 0; i < kPiecesPerWave; ++i) {
-        const uint32_t off = dma_off[i] + (w == 2 ? tile_step : 0u);
-        cold[w][i][0] = __builtin_amdgcn_raw_buffer_load_b128(w == 1 ? v_rs : k_rs, off, 0, 0);
-        cold[w][i][1] = __builtin_amdgcn_raw_buffer_load_b128(w == 1 ? v_rs : k_rs, off + 16u, 0, 0);
+        load_kv_f32_as_f16(cold[w][i][0], cold[w][i][1], w == 1 ? v_srd : k_srd, dma_off[i] + (w == 2 ? tile_step : 0u));
       }
     }
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
 #pragma unroll
       for (int i = 0; i < kPiecesPerWave; ++i) {
-        *FLASH_LDS_CAST(f16x8, (w == 1 ? v_ring : k_ring) + (w == 2 ? kTileBytes : 0) + i * 1024 + lds_lane) =
-            q_frag_from_f32(cold[w][i][0], cold[w][i][1]);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cold[w][i][0]), "+v"(cold[w][i][1]) : : "memory");
+        *FLASH_LDS_CAST(u32x4, (w == 1 ? v_ring : k_ring) + (w == 2 ? kTileBytes : 0) + i * 1024 + lds_lane) =
+            u32x4{cold[w][i][0][0], cold[w][i][0][1], cold[w][i][1][0], cold[w][i][1][1]};
       }
     }
   } else {
@@ -968,7 +993,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16(const FwdPara
       constexpr int kFirstWrite = kSlots - 2 * kPiecesPerWave - 2;
       const bool go = !MASKED || (v_side ? t + 1 < nt : t + 2 < nt);  // the unmasked iterations always stage
       if (n >= 1 && n < 1 + 2 * kPiecesPerWave && (n - 1) % 2 == 0) {
-        if (go) load_piece(v_side ? v_rs : k_rs, v_side ? t + 1 : t + 2, (n - 1) / 2);
+        if (go) load_piece(v_side ? v_srd : k_srd, v_side ? t + 1 : t + 2, (n - 1) / 2);
       }
       if (n >= kFirstWrite && n < kFirstWrite + 2 * kPiecesPerWave && (n - kFirstWrite) % 2 == 0) {
         if (go) write_piece(v_side ? v_ring : k_ring, v_side ? s1 : s2, (n - kFirstWrite) / 2);
@@ -1056,6 +1081,16 @@ struct CfgP : Cfg<D> {
 // that voff + soff stays inside the buffer whenever voff does.
 __device__ __forceinline__ void load_q_raw(f16x8& dst, srd_t srd, uint32_t voff, uint32_t soff) {
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+
+// Eight 16-bit values, held as two register pairs of the accumulation file, to 16 bytes of LDS at
+// addr + off (off: a compile-time constant after inlining, below 64 KiB).  Not tracked by the compiler: a
+// barrier that publishes the data waits with its own s_waitcnt lgkmcnt(0).
+__device__ __forceinline__ void lds_write_chunk(uint32_t addr, const u32x2& lo, const u32x2& hi, uint32_t off) {
+  asm volatile("ds_write_b64 %0, %1 offset:%3\n\tds_write_b64 %0, %2 offset:%3+8"
+               :
+               : "v"(addr), "a"(lo), "a"(hi), "i"(off)
+               : "memory");
 }
 
 // Wait for the Q loads: all vector memory operations but the YOUNGER most recent ones.  The registers
@@ -1150,52 +1185,56 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const int src = (ci % C::kChunks) ^ swz<D>(row);
     dma_off[i] = (src * 8 < d) ? (uint32_t)row * row_bytes + (uint32_t)src * 8u * kKVElem : kOob;
   }
-  // fp32 K/V: the two halves of piece i's chunk land in registers and are rounded to fp16 and written to
-  // the place the DMA would have filled.  Where the loop leaves vector registers free (d = 64) these are
-  // ordinary loads: the compiler tracks them and waits where they are converted.  In the d = 128 kernels
-  // the vector registers are all taken: there the loads land in ACCUMULATION registers (32 of the 48 that
-  // O^T, Q and the row sums leave free in the four-wave layout, 16 of 21 in the eight-wave layout, whose
-  // waves stage half as much each), issued from inline asm, which the compiler neither sees nor waits for: write_piece waits
-  // itself, counting the younger loads of the same tile (vector memory operations complete in order), and
-  // the values pass through v_accvgpr_read on their way to the conversion.
-  constexpr bool kLandAcc = KV32 && D == 128;
+  // fp32 K/V: the memory pipeline converts.  A typed buffer load with a 16-bit destination
+  // (tbuffer_load_format_d16_xyzw on 32_32_32_32 FLOAT data) reads four fp32 values per lane and delivers
+  // them as four fp16 values in two registers, rounded to nearest even like v_cvt_pk_f16_f32 (compared value
+  // by value, ties and subnormals included, in tools/microbench/d16_load.cpp; finite values beyond the fp16
+  // range come out as +-65504 where the instruction gives +-inf), at the rate of a plain 128-bit load.  Two
+  // of them fetch the 32 source bytes of piece i's chunk; they land in ACCUMULATION registers, which LDS
+  // instructions take as data directly: two ds_write_b64 put the chunk where the DMA would have put it.  No
+  // vector-ALU instruction touches the tile on its way (the previous form: 128-bit loads, v_accvgpr_read of
+  // every register, v_cvt_pk_f16_f32: 24 vector instructions per chunk).  The compiler sees neither the
+  // loads nor the LDS writes: write_piece waits by counting the younger loads of the same tile (vector
+  // memory loads complete in order), the barriers that publish a tile wait for the LDS writes themselves.
   auto kv_srd = [&](const void* base, uint32_t hd) __attribute__((always_inline)) {
     return make_srd((const char*)base + (size_t)hd * head_elems * kKVElem, head_bytes * (kKVElem / 2u));
   };
-  u32x4 land[KV32 ? kPiecesPerWave : 1][2];
+  u32x2 land_kv[1][KV32 ? kPiecesPerWave : 1][2];
   // Tile t of the head behind `srd`.  Whole tiles only: the tile offset bypasses the range check as a scalar
   // offset, so no per-lane address arithmetic (a chunk beyond d stays out of range through its per-lane
   // offset).
-  auto load_piece = [&](const srd_t srd, int t, int i) __attribute__((always_inline)) {
+  auto load_piece = [&](bool v_side, const srd_t srd, int t, int i) __attribute__((always_inline)) {
+    u32x2 (&land)[KV32 ? kPiecesPerWave : 1][2] = land_kv[0];
+    (void)v_side;
     const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)t * tile_step);
-    if constexpr (kLandAcc) {
-      // (s_nop 4: with the scalar registers as short as they are in this kernel the compiler keeps uniform
-      // values in vector registers and moves them over right in front of their use; see settle_scalars)
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:16"
-                   : "=a"(land[i][0]), "=a"(land[i][1])
-                   : "v"(dma_off[i]), "s"(srd), "s"(soff)
-                   : "memory");
-    } else {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(((uint64_t)(srd[1] & 0xffffu) << 32) | srd[0]), 0, srd[2], 0x00020000);
-      land[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i], soff, 0);
-      land[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i] + 16u, soff, 0);
-    }
+    // (s_nop 4: with the scalar registers as short as they are in this kernel the compiler keeps uniform
+    // values in vector registers and moves them over right in front of their use; see settle_scalars)
+    asm volatile(
+        "s_nop 4\n\t"
+        "tbuffer_load_format_d16_xyzw %0, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen\n\t"
+        "tbuffer_load_format_d16_xyzw %1, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen offset:16"
+        : "=a"(land[i][0]), "=a"(land[i][1])
+        : "v"(dma_off[i]), "s"(srd), "s"(soff)
+        : "memory");
   };
-  const uint32_t lds_lane = (uint32_t)(wave * kPiecesPerWave * 1024 + lane * 16);
-  // `younger`: loads issued after this piece's two
-  auto wait_piece = [&](int i, int younger) __attribute__((always_inline)) {
+  // this lane's 16 bytes of its wave's first piece in slot 0 of either ring; slot and piece add a constant
+  const uint32_t lds_k_lane = (uint32_t)(uintptr_t)k_ring + (uint32_t)(wave * kPiecesPerWave * 1024 + lane * 16);
+  const uint32_t lds_v_lane = (uint32_t)(uintptr_t)v_ring + (uint32_t)(wave * kPiecesPerWave * 1024 + lane * 16);
+  // `younger`: vector memory loads issued after this piece's two and before this wait
+#define FLASH_WAIT_CASE(N) \
+  case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+a"(lo), "+a"(hi) : : "memory"); break;
+  auto wait_piece = [&](u32x2& lo, u32x2& hi, int younger) __attribute__((always_inline)) {
     switch (younger) {  // (an immediate operand)
-      case 0: asm volatile("s_waitcnt vmcnt(0)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
-      case 2: asm volatile("s_waitcnt vmcnt(2)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
-      case 4: asm volatile("s_waitcnt vmcnt(4)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
-      default: asm volatile("s_waitcnt vmcnt(6)" : "+a"(land[i][0]), "+a"(land[i][1]) : : "memory"); break;
+      FLASH_WAIT_CASE(0) FLASH_WAIT_CASE(2) FLASH_WAIT_CASE(4) FLASH_WAIT_CASE(6) FLASH_WAIT_CASE(8)
+      FLASH_WAIT_CASE(10) FLASH_WAIT_CASE(12)
+      default: asm volatile("s_waitcnt vmcnt(14)" : "+a"(lo), "+a"(hi) : : "memory"); break;
     }
   };
-  auto write_piece = [&](bool v_side, int slot, int i) __attribute__((always_inline)) {
-    if constexpr (kLandAcc) wait_piece(i, 2 * (kPiecesPerWave - 1 - i));
-    *FLASH_LDS_CAST(f16x8, (v_side ? v_ring : k_ring) + slot * kTileBytes + i * 1024 + lds_lane) =
-        q_frag_from_f32(land[i][0], land[i][1]);
+#undef FLASH_WAIT_CASE
+  auto write_piece = [&](bool v_side, int slot, int i, int younger) __attribute__((always_inline)) {
+    u32x2 (&land)[KV32 ? kPiecesPerWave : 1][2] = land_kv[0];
+    if constexpr ((kKnock & 256) == 0) wait_piece(land[i][0], land[i][1], younger);  // (256: timing only, what the waits cost)
+    lds_write_chunk(v_side ? lds_v_lane : lds_k_lane, land[i][0], land[i][1], (uint32_t)(slot * kTileBytes + i * 1024));
   };
   // LDS address of this wave's first piece in slot 0 of the K ring; the ring (K or V), the slot and the
   // piece number add a compile-time constant
@@ -1207,7 +1246,11 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     dma_piece_at(srd, dma_off[i], soff, lds_wave_base, (uint32_t)(((v_side ? kRingP : 0) + slot) * kTileBytes + i * 1024));
   };
   auto staged_barrier = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (KV32) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the tile's LDS writes are this wave's own)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
   };
   auto head_of = [&](uint32_t it) __attribute__((always_inline)) { return it / (uint32_t)p.nqt; };
@@ -1317,38 +1360,52 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     fetch_q(item);
   }
   if constexpr (KV32) {
-    // K tile 0 and V tile 0 in flight together with the first half of Q, K tile 1 with the second half
-    // (everything at once does not fit the register file next to the loop's long-lived values)
-    const __amdgpu_buffer_rsrc_t k_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.k + (size_t)head_of(item) * head_elems * kKVElem), 0, head_bytes * (kKVElem / 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((const char*)p.v + (size_t)head_of(item) * head_elems * kKVElem), 0, head_bytes * (kKVElem / 2u), 0x00020000);
-    u32x4 cold[2][kPiecesPerWave][2];
-    auto cold_load = [&](int w, const __amdgpu_buffer_rsrc_t rs, uint32_t toff) __attribute__((always_inline)) {
+    // K tiles 0 and 1 and V tile 0 in flight together with the first half of Q, through the same converting
+    // loads as in the loop; here they land in vector registers (the score and probability registers are
+    // still free) and go to LDS through ordinary stores.
+    u32x2 cold[3][kPiecesPerWave][2];
+    auto cold_load = [&](int w, const srd_t srd, uint32_t toff) __attribute__((always_inline)) {
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(toff);
 #pragma unroll
       for (int i = 0; i < kPiecesPerWave; ++i) {
-        cold[w][i][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i] + toff, 0, 0);
-        cold[w][i][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, dma_off[i] + toff + 16u, 0, 0);
+        asm volatile(
+            "s_nop 4\n\t"
+            "tbuffer_load_format_d16_xyzw %0, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen\n\t"
+            "tbuffer_load_format_d16_xyzw %1, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen offset:16"
+            : "=&v"(cold[w][i][0]), "=&v"(cold[w][i][1])
+            : "v"(dma_off[i]), "s"(srd), "s"(soff)
+            : "memory");
       }
     };
     auto cold_write = [&](int w, lds_char* dst) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < kPiecesPerWave; ++i)
-        *FLASH_LDS_CAST(f16x8, dst + i * 1024 + lds_lane) = q_frag_from_f32(cold[w][i][0], cold[w][i][1]);
+      for (int i = 0; i < kPiecesPerWave; ++i) {
+        const u32x4 chunk = {cold[w][i][0][0], cold[w][i][0][1], cold[w][i][1][0], cold[w][i][1][1]};
+        *FLASH_LDS_CAST(u32x4, dst + i * 1024 + (wave * kPiecesPerWave * 1024 + lane * 16)) = chunk;
+      }
     };
-    cold_load(0, k_rs, 0u);
-    cold_load(1, v_rs, 0u);
+    cold_load(0, k_srd, 0u);
+    cold_load(1, v_srd, 0u);
+    cold_load(2, k_srd, tile_step);
     __builtin_amdgcn_sched_barrier(0);
     convert_q32(0);
     if constexpr (kQPhases > 1) fetch_q32(item, 1);
     __builtin_amdgcn_sched_barrier(0);
+    // the cold loads are older than the second half of Q: wait for everything but that
+    {
+      constexpr int kYounger = kQPhases > 1 ? 2 * kQPerPhase * kKS : 0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int i = 0; i < kPiecesPerWave; ++i)
+          asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cold[w][i][0]), "+v"(cold[w][i][1]) : "n"(kYounger) : "memory");
+      }
+    }
     cold_write(0, k_ring);
     cold_write(1, v_ring);
-    __builtin_amdgcn_sched_barrier(0);
-    cold_load(0, k_rs, tile_step);
+    cold_write(2, k_ring + kTileBytes);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (kQPhases > 1) convert_q32(1);
-    cold_write(0, k_ring + kTileBytes);
     __builtin_amdgcn_sched_barrier(0);
   } else {
 #pragma unroll
@@ -1483,17 +1540,21 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
           }
         }
       };
-      // fp32 K/V: one tile per step, the K tile in the first and the V tile in the second; loads in the
-      // step's first slots, conversion and LDS writes in its last ones
+      // fp32 K/V: one tile per step, the K tile in the first and the V tile in the second; its loads go out
+      // in the step's first slots and its LDS writes sit in the last ones, a step's worth of matrix work
+      // (about a microsecond) later.  A piece's wait counts the loads behind it, the rest of its own tile.
+      // (Both tiles' loads in the first step and both tiles' writes at the end of the second, or the V loads
+      // half a step early, were built and measured: 2-4 % slower and the same, respectively.)
       auto vec_hook = [&](int n, bool v_side) __attribute__((always_inline)) {
         constexpr int kSlots = (2 * kKS + kDv16) * kQ16;
         constexpr int kFirstWrite = kSlots - 2 * kPiecesPerWave - 2;
         const bool go = !CROSS || (v_side ? v_go : k_go);
         if (n >= 1 && n < 1 + 2 * kPiecesPerWave && (n - 1) % 2 == 0) {
-          if (go) load_piece(v_side ? vs_srd : ks_srd, v_side ? v_tile : k_tile, (n - 1) / 2);
+          if (go) load_piece(v_side, v_side ? vs_srd : ks_srd, v_side ? v_tile : k_tile, (n - 1) / 2);
         }
         if (n >= kFirstWrite && n < kFirstWrite + 2 * kPiecesPerWave && (n - kFirstWrite) % 2 == 0) {
-          if (go) write_piece(v_side, v_side ? S1 : S2, (n - kFirstWrite) / 2);
+          const int i = (n - kFirstWrite) / 2;
+          if (go) write_piece(v_side, v_side ? S1 : S2, i, 2 * (kPiecesPerWave - 1 - i));
         }
       };
       auto hook1 = [&](int n) __attribute__((always_inline)) {
@@ -1529,6 +1590,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         // wait for this wave's staging pieces, which are older than the Q loads, but not for those
         if (has_next && !QF32) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQ16 * kKS) : "memory");
+        } else if constexpr (KV32) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

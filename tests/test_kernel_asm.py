@@ -115,16 +115,17 @@ def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
         d = 128 if "Li128E" in name else 64
         nq = TUNED[frag][2]
         base = nq * d * 3 // 8          # O^T: nq * d / 4 registers, Q: nq * d / 8
-        if "Lb1" in name and d == 128 and "m16pI" in name:
-            # persistent kernel: fp32 K/V tiles land in accumulation registers above the row sums and are read out of them for
-            # the conversion: reads of exactly those registers, never a write
-            assert all(m.startswith("v_accvgpr_read") for m in moves), (name, moves[:3])
-            landing = _acc_regs(" ".join(m.split(None, 1)[1].split(",")[1] for m in moves))
-            assert landing and min(landing) >= base + 4 * nq and len(landing) == 32, (name, sorted(landing))
-            loads = [l for l in hot if l.startswith("buffer_load")]
-            assert loads and all(_acc_regs(l.split(None, 1)[1].split(",")[0]) <= landing for l in loads), name
-        else:
-            assert not moves, f"{name}: {len(moves)} VGPR<->AGPR moves in the main loop, e.g. {moves[:3]}"
+        assert not moves, f"{name}: {len(moves)} VGPR<->AGPR moves in the main loop, e.g. {moves[:3]}"
+        if "Lb1" in name and "m16pI" in name:
+            # persistent kernel on fp32 K/V: the tiles arrive through converting loads (typed, 16-bit destination)
+            # in accumulation registers and go to LDS straight from there: no vector-ALU instruction in between
+            loads = [l for l in hot if l.startswith("tbuffer_load_format_d16_xyzw")]
+            landing = set().union(*(_acc_regs(l.split(None, 1)[1].split(",")[0]) for l in loads)) if loads else set()
+            assert loads and landing, name
+            writes = [l for l in hot if l.startswith("ds_write_b64")]
+            assert len(writes) == len(loads), (name, len(loads), len(writes))
+            assert all(_acc_regs(w.split(None, 1)[1].split(",")[1]) <= landing for w in writes), name
+            assert not any(l.startswith("buffer_load_dwordx4") and " lds" not in l for l in hot), name
         assert not any("scratch_" in l or "buffer_store" in l for l in hot), name
         # one barrier per tile iteration
         assert sum(l.startswith("s_barrier") for l in hot) in (TUNED[frag][1], TUNED[frag][1] - 1), name
