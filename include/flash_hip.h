@@ -72,7 +72,7 @@ typedef struct flash_launch_info {
   uint32_t grid_z;       /* ceil(N / Br): grid = the work items; when N % Br == 0 a persistent kernel
                             walks them with one workgroup per CU      (gridDim().z)  */
   uint32_t staging;      /* how K/V tiles reach LDS: 0 = element loads through registers (any head dim, any
-                            alignment), 1 = 128-bit fp32 loads through registers, rounded to fp16 on the way
+                            alignment), 1 = fp32 tensors through registers, rounded to fp16 on the way by converting loads
                             (fp32 tensors, d % 8 == 0), 2 = direct global->LDS loads (buffer_load ... lds;
                             fp16 / bfloat16 tensors, and fp32 tensors behind the conversion pass) */
   uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */
@@ -132,7 +132,10 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o,
  * Q, K, V are rounded to fp16 (round-to-nearest-even) while they are staged into LDS/registers, the
  * arithmetic is the same fp16-MFMA / fp32-accumulate pipeline, O is written as fp32.  No workspace, one
  * kernel.  With d % 8 == 0 and 16-byte-aligned tensors the 16x16x32 kernels of flash_fwd_f16 do the
- * staging with 128-bit loads (whole query tiles on the persistent kernel); otherwise element by element.
+ * staging (whole query tiles on the persistent kernel) and K and V are converted by the loads themselves
+ * (typed buffer loads with a 16-bit destination: same rounding, but a finite value beyond the fp16 range
+ * arrives as +-65504 where a conversion instruction, the conversion pass of flash_fwd_f32_ws and torch's
+ * .half() give +-inf; such inputs have no meaningful result on any route); otherwise element by element.
  */
 int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
                   int64_t B, int64_t H, int64_t N, int64_t d,

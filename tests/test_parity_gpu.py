@@ -165,6 +165,28 @@ def test_fp32_register_staged_route(fa, oracle, torch_gpu):
             assert_close(o[b, h], ref, f"fp32 register-staged {shape} head {(b, h)}")
 
 
+def test_fp32_values_beyond_the_fp16_range_saturate_on_the_register_staged_route(fa, oracle, torch_gpu):
+    """K and V of fp32 callers are converted by the loads themselves on this route (typed buffer loads with a
+    16-bit destination): same rounding as a conversion instruction, except that a finite value beyond the fp16
+    range arrives as +-65504 instead of +-inf.  Pinned here on V (where the effect is linear): the result is
+    the plain formula on V clipped to the fp16 range, and finite."""
+    torch = torch_gpu
+    for shape in ((1, 2, 256, 64), (1, 2, 512, 128), (1, 1, 300, 128)):     # persistent d = 64 / 128, ragged
+        assert fa.launch_info(*shape, entry=fa.ENTRY_F32).staging == 1
+        rng = np.random.default_rng(shape[2])
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+        v[0, 0, 5, 3] = 1.0e6
+        v[0, -1, 77, 0] = -3.0e5
+        v[0, 0, 200, 9] = 65519.0          # rounds to 65504 either way
+        o = run_abi(fa, torch, q, k, v, fa.KernelType.mma_qreg_async, torch.float32)
+        assert np.isfinite(o).all()
+        ref = oracle.attn_naive(oracle.round_f16(q), oracle.round_f16(k), oracle.round_f16(np.clip(v, -65504.0, 65504.0)))
+        # outputs reach the thousands here: the allclose form of the bar, |res - ref| <= 2e-3 + 1e-2 |ref|
+        err = np.abs(o.astype(np.float64) - ref)
+        assert (err <= ATOL + RTOL * np.abs(ref)).all(), f"{shape}: {int((err > ATOL + RTOL * np.abs(ref)).sum())} elements off"
+        assert np.abs(ref).max() > 100.0     # the clipped values do dominate some rows
+
+
 def test_fp32_workspace_path_rounds_like_the_in_kernel_path(fa, oracle, torch_gpu, monkeypatch):
     """fp32 tensors that are NOT fp16-representable: the conversion pass into the workspace and the
     in-kernel conversion round the same way (to nearest even), so both agree with the oracle on the
