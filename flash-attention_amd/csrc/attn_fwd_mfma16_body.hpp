@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const int n16 = lane & 15;
   const int g = lane >> 4;
   const int N = p.N, d = p.d;
-  const ScaleSplit sc{p.s_scale, p.defer_thr};
+  const ScaleSplit sc_all{p.s_scale, p.defer_thr};
   const int nt = N / kBc;  // multiple of 4
   if (tid < kOverflowWords) overflowed[tid] = 0u;  // published by the barrier that ends the cold start
   uint32_t ordinal = 0;                            // of the current item among this workgroup's items
@@ -1172,6 +1172,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   // kernel: the two then share no vector register, and neither constrains the other's allocation.
   auto sweep = [&](auto sparse_tag, const uint32_t start_item, const bool chain) __attribute__((always_inline)) {
   constexpr bool SPARSE = decltype(sparse_tag)::value;
+  // A sweep that looks at few blocks moves its references sooner (half the deferral threshold: 4 exp2 units):
+  // what a look has seen then lies at most that far above the reference, and 12 units remain before a
+  // probability in a block nobody looked at leaves the fp16 range.
+  const ScaleSplit sc{sc_all.c, SPARSE ? 0.5f * sc_all.thr : sc_all.thr};
   // (the lane's number inside its wave, counted by the hardware: no register carries it from sweep to sweep)
   int lane_opaque = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   asm volatile("" : "+v"(lane_opaque));
