@@ -1111,9 +1111,6 @@ __device__ __forceinline__ void wait_q(f16x8 (&qf)[kQ16][KS]) {
   }
 }
 
-constexpr int kOverflowWords = 32;  // 1024 item ordinals; a workgroup with more items shares bits (a set bit
-                                    // then repeats every item that maps to it, which only costs time)
-
 // KV32: as in attn_fwd_kernel_m16, K and V are the caller's fp32 tensors and every wave converts its share
 // of a tile on its way into LDS (TO = float, four-wave layout).
 template <int D, typename TO = f16, bool KV32 = false>
@@ -1125,8 +1122,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   constexpr int kPiecesPerWave = C::kPiecesPerWave;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   lds_char* const smem = (lds_char*)smem_raw;
-  // one bit per work item of this workgroup (ordinal modulo the size): set when the item's first pass overflowed
-  __shared__ uint32_t overflowed[kOverflowWords];
+  // set by any wave whose item overflowed in the first sweep (see below)
+  __shared__ uint32_t overflowed;
   FLASH_STAMP(stamp_entry);
 
   // Items are dealt to the 8 XCDs in contiguous ranges (workgroup ids equal mod 8 share an XCD);
@@ -1149,8 +1146,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const int N = p.N, d = p.d;
   const ScaleSplit sc_all{p.s_scale, p.defer_thr};
   const int nt = N / kBc;  // multiple of 4
-  if (tid < kOverflowWords) overflowed[tid] = 0u;  // published by the barrier that ends the cold start
-  uint32_t ordinal = 0;                            // of the current item among this workgroup's items
+  if (tid == 0) overflowed = 0u;  // published by the barrier that ends the cold start
+  // where the first sweep ended: the item it was working on, and whether it gave that item up
+  uint32_t sweep_end_item = 0u;
+  bool sweep_gave_up = false;
 
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
@@ -1163,14 +1162,14 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   lds_char* const k_ring = smem;
   lds_char* const v_ring = smem + kRingP * kTileBytes;
 
-  // A sweep over work items: `start_item` from a cold start, then (chain) every wgs_on_xcd-th item after it
-  // with the staging running across the item boundaries.  SPARSE: only a few steps of an item take the
-  // running maximum (see below); an item whose probabilities left the fp16 range on the way is marked in
-  // `overflowed` and its output is not valid.
+  // A sweep over work items: `start_item` from a cold start, then every wgs_on_xcd-th item after it with the
+  // staging running across the item boundaries.  SPARSE: only a few steps of an item take the running
+  // maximum (see below); an item whose probabilities left the fp16 range on the way sets `overflowed`, its
+  // output is not valid, and the sweep ends two K/V tiles into the item after it.
   // Everything a lane keeps for a whole sweep (LDS and buffer offsets of its fragments, pieces and Q chunks)
   // is worked out inside, from a lane number the compiler cannot recognise as the same in both sweeps of the
   // kernel: the two then share no vector register, and neither constrains the other's allocation.
-  auto sweep = [&](auto sparse_tag, const uint32_t start_item, const bool chain) __attribute__((always_inline)) {
+  auto sweep = [&](auto sparse_tag, const uint32_t start_item) __attribute__((always_inline)) {
   constexpr bool SPARSE = decltype(sparse_tag)::value;
   // A sweep that looks at few blocks moves its references sooner (half the deferral threshold: 4 exp2 units):
   // what a look has seen then lies at most that far above the reference, and 12 units remain before a
@@ -1453,7 +1452,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   for (;;) {
     FLASH_STAMP(stamp_item);
     const uint32_t next_item = item + wgs_on_xcd;
-    const bool has_next = chain && next_item < hi;
+    const bool has_next = next_item < hi;
     const uint32_t next_head = has_next ? head_of(next_item) : head_of(item);
     const uint32_t head = head_of(item), qt = item - head * (uint32_t)p.nqt;
     TO* oh = (TO*)p.o + (size_t)head * head_elems;
@@ -1619,7 +1618,20 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     constexpr integral_constant<int, !SPARSE ? 3 : (kTrackMode == 1 ? FLASH_TRACK_LOOP : 0)> trk_loop{};
     constexpr integral_constant<int, !SPARSE ? 3 : 0> trk_rest{};
     tile_iter(integral_constant<int, 0>{}, no, no, yes, trk_first, 0);
+    // Every wave has passed the barrier that ends tile 0, hence finished the item before, output and verdict
+    // included: all waves read the same value here.  The value is looked at one tile later, when it has
+    // long arrived.  (Timing-only knock-out builds compute garbage on purpose and carry on.)
+    uint32_t verdict = 0u;
+    if constexpr (SPARSE && kKnock == 0) {
+      verdict = __hip_atomic_load(&overflowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     tile_iter(integral_constant<int, 1>{}, no, no, no, trk_rest, 1);
+    if constexpr (SPARSE && kKnock == 0) {
+      if (item != start_item && __builtin_expect(__builtin_amdgcn_readfirstlane(verdict) != 0u, 0)) {
+        sweep_gave_up = true;
+        break;
+      }
+    }
     for (int t = 2; t + 2 < nt; t += 4) {
       tile_iter(integral_constant<int, 2>{}, no, no, no, trk_loop, t);
       tile_iter(integral_constant<int, 3>{}, no, no, no, trk_rest, t + 1);
@@ -1677,10 +1689,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       // A probability beyond the fp16 range (a score more than 16 exp2 units above a reference that most
       // steps no longer update) shows as an infinite row sum: the item is marked and computed again below.
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst >= 0x7f800000u) != 0, 0)) {
-        if (lane == 0) {
-          __hip_atomic_fetch_or(&overflowed[(ordinal >> 5) % kOverflowWords], 1u << (ordinal & 31u), __ATOMIC_RELAXED,
-                                __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (lane == 0) __hip_atomic_store(&overflowed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
 #if defined(FLASH_PHASE_STAMPS)
@@ -1712,34 +1721,30 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     ++n_items;
 #endif
     item = next_item;
-    ++ordinal;
     k_srd = kv_srd(p.k, next_head);
     v_srd = kv_srd(p.v, next_head);
   }
+  sweep_end_item = item;
   };  // sweep
 
   if constexpr (kTrackMode == 0) {
-    sweep(std::false_type{}, first_item, true);
+    sweep(std::false_type{}, first_item);
   } else {
-    sweep(std::true_type{}, first_item, true);
-    // ---- second pass: the items whose first pass overflowed, one at a time from a cold start, with the
-    // running maximum taken in every step (no input makes that pass overflow).  Their output rows are
-    // written again by the waves that wrote them first, after those stores have completed.
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    sweep(std::true_type{}, first_item);
+    // ---- second sweep: from the item whose first pass overflowed to the end of the list, from a cold start,
+    // with the running maximum taken in every step (no input makes that pass overflow).  Inputs that overflow
+    // in one item tend to do so in the next: the rest of the list is not tried the cheap way again, and the
+    // price of such an input is one item (and two K/V tiles) per workgroup computed twice.  The item's output
+    // rows are written again by the waves that wrote them first, after those stores have completed; matrix
+    // instructions of a sweep that gave up inside an item have drained behind the wait states.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
     __syncthreads();
-    uint32_t any = 0u;
-    // (timing-only knock-out builds compute garbage on purpose: their items are not repeated)
-#pragma unroll
-    for (int w = 0; w < kOverflowWords; ++w) any |= kKnock == 0 ? overflowed[w] : 0u;
-    if (__builtin_expect(__builtin_amdgcn_readfirstlane(any) != 0u, 0)) {
-      uint32_t ord = 0;
-#pragma unroll 1
-      for (uint32_t it = first_item; it < hi; it += wgs_on_xcd, ++ord) {
-        const uint32_t word = __builtin_amdgcn_readfirstlane(overflowed[(ord >> 5) % kOverflowWords]);
-        if (((word >> (ord & 31u)) & 1u) == 0u) continue;
-        __syncthreads();  // the last V fragments of the item before have been read
-        sweep(std::false_type{}, it, false);
-      }
+    const bool marked =
+        __builtin_amdgcn_readfirstlane(__hip_atomic_load(&overflowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u;
+    // a sweep that gave up was one item past the one that overflowed; one that reached the end of its list
+    // has the verdict on its last item still to read
+    if (__builtin_expect(kKnock == 0 && (sweep_gave_up || marked), 0)) {
+      sweep(std::false_type{}, sweep_gave_up ? sweep_end_item - wgs_on_xcd : sweep_end_item);
     }
   }
 #endif  // __HIP_DEVICE_COMPILE__

@@ -64,7 +64,7 @@ typedef struct flash_launch_info {
   uint32_t tile_q;       /* Br: Q rows per workgroup: 256, or 512 for head dims <= 64 with N % 512 == 0 (tileSize().y) */
   uint32_t tile_d;       /* head dim padded to the compiled tile     (tileSize().z) */
   uint32_t lds_bytes;    /* dynamic LDS per workgroup                (sramSize()); persistent kernels hold
-                            128 bytes of static LDS besides (their overflow marks, see `persistent`) */
+                            4 bytes of static LDS besides (their overflow flag, see `persistent`) */
   uint32_t block_x;      /* lanes per wave = 64                      (blockDim().x) */
   uint32_t block_y;      /* waves per workgroup: 4, or 8 for whole-tile shapes with d > 64 (blockDim().y) */
   uint32_t grid_x;       /* B                                        (gridDim().x)  */
@@ -82,9 +82,10 @@ typedef struct flash_launch_info {
                             A persistent kernel takes the softmax's running maximum in a few steps of an item
                             only; an item in which a probability left the fp16 range on the way (a score more
                             than 16 exp2 units above everything those steps saw) is computed a second time by
-                            the same workgroup, with the maximum in every step, before the kernel ends.  The
-                            result is the same either way; the time of a call therefore depends on its data
-                            (up to about twice on inputs built so that every item overflows). */
+                            the same workgroup, with the maximum in every step, and so is the rest of that
+                            workgroup's list (once).  The result is the same either way; the time of a call
+                            therefore depends on its data (8 % at (8,96,4096,128), up to 40 % at N = 512, on
+                            inputs built so that every workgroup meets such an item). */
 } flash_launch_info;
 
 /* Which entry point a geometry query describes. */

@@ -3,8 +3,9 @@
 The first pass over a work item takes the running maximum in a few steps only (both steps of K/V tile 0,
 then the second step of every fourth tile from tile 2 on, each looking at the NEXT 32 keys: key blocks 1, 2,
 6, 14, 22, ...).  Scores in any other block never move the reference; a probability that leaves the fp16
-range on the way (a score more than 16 exp2 units above the reference) shows as an infinite row sum, the
-item is marked and computed again with the maximum taken in every step.  These tests plant scores where the
+range on the way (a score more than 16 exp2 units above the reference) shows as an infinite row sum.  The
+workgroup then stops its first sweep (two K/V tiles into the next item) and computes that item and the rest
+of its list again from a cold start with the maximum taken in every step.  These tests plant scores where the
 first pass does not look and require the result of the plain formula in every case.
 """
 import numpy as np
@@ -83,15 +84,18 @@ def test_scores_that_rise_along_the_sequence(fa, oracle, torch_gpu, monkeypatch,
             check_heads(fa, oracle, torch_gpu, q, k, v, torch_gpu.float16, f"{label} drift {shape} {env}")
 
 
-def test_more_items_per_workgroup_than_overflow_bits(fa, oracle, torch_gpu, monkeypatch):
-    """Eight workgroups (FLASH_HIP_GRID) share 8400 one-tile items, 1050 each: item ordinals beyond 1024 share
-    their overflow bit with ordinals 0..25.  Peaks that overflow the first pass sit in heads all over the
-    range, among them ordinals that alias (the partner is then computed again too, to the same result)."""
+def test_long_item_lists_with_overflow_at_any_place(fa, oracle, torch_gpu, monkeypatch):
+    """Eight workgroups (FLASH_HIP_GRID) share 8400 one-tile items, 1050 each.  Peaks that overflow the first
+    pass sit in heads all over the range: in a workgroup's first item, its second, its last, and in the middle
+    of a list (the first sweep ends there and the second takes over for the rest); some workgroups meet none."""
     shape = (1, 8400, 256, 64)
     B, H, N, d = shape
     rng = np.random.default_rng(99)
     q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
-    hot = [0, 7, 8, 9, 1023, 1030, 1049, 4100, 8191, 8192, 8199, 8200, 8399]   # 1030, 1049, 8399: ordinals >= 1024
+    # items are dealt to XCDs in ranges of 1050 heads and one workgroup serves each range here: the first finds
+    # a peak in its first item, the second in its second, the third and the last in their last, the fourth and
+    # fifth in the middle of their lists, the sixth and seventh nowhere
+    hot = [0, 7, 1051, 3149, 4100, 5000, 5249, 8399]
     for h in hot:
         q1, k1 = q[:, h:h + 1], k[:, h:h + 1]
         plant(q1, k1, 17, 120, 40.0)
@@ -100,14 +104,14 @@ def test_more_items_per_workgroup_than_overflow_bits(fa, oracle, torch_gpu, monk
     with routing(fa, monkeypatch, FLASH_HIP_GRID=8):
         o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, torch_gpu.float16)
     assert np.isfinite(o).all()
-    for h in sorted(set(hot + [1, 6, 10, 25, 1024, 5000, 7375, 8201])):   # 6, 25, 7375 share bits with 1030, 1049, 8399
+    for h in sorted(set(hot + [1, 6, 8, 1049, 1050, 1052, 2100, 3148, 3150, 4099, 4101, 5248, 5250, 6300, 7349, 7350, 8398])):
         ref = oracle.attn_naive(*(x[:, h:h + 1] for x in (q, k, v)))[0, 0]
         assert_close(o[0, h], ref, f"head {h} of {shape} on eight workgroups")
 
 
 def test_nan_in_one_head_stays_there_and_the_kernel_returns(fa, oracle, torch_gpu):
-    """A NaN in K poisons every query of its head (as it does in the plain formula); the items of that head
-    are marked, computed again (NaN again) and left; every other head is untouched."""
+    """A NaN in K poisons every query of its head (as it does in the plain formula); the first sweep stops at
+    an item of that head, the second computes it again (NaN again) and goes on; every other head is untouched."""
     shape = (1, 6, 512, 128)
     rng = np.random.default_rng(5)
     q, k, v = (oracle.round_f16(rng.standard_normal(shape).astype(np.float32)) for _ in range(3))
