@@ -109,6 +109,48 @@ def test_long_item_lists_with_overflow_at_any_place(fa, oracle, torch_gpu, monke
         assert_close(o[0, h], ref, f"head {h} of {shape} on eight workgroups")
 
 
+# (shape, dtype name, workspace, routing environment): one case per persistent kernel, ten items per workgroup
+RESUME_CASES = [
+    ((1, 20, 1024, 128), "float16", False, {}),                               # eight waves x 32 rows
+    ((1, 20, 1024, 128), "float16", False, {"FLASH_HIP_WIDE_MAX_N": "0"}),    # four waves x 64 rows
+    ((1, 40, 1024, 64), "float16", False, {}),                                # four waves x 128 rows (512-row items)
+    ((1, 20, 1024, 64), "float16", False, {"FLASH_HIP_TALL": "0"}),           # four waves x 64 rows, d = 64
+    ((1, 20, 1024, 128), "float32", False, {}),                               # fp32 K/V converted in the kernel
+    ((1, 20, 1024, 64), "float32", False, {}),
+    ((1, 20, 1024, 128), "float32", True, {"FLASH_HIP_VEC_MAX_N": "0"}),      # conversion pass, fp32 Q and O in the kernel
+    ((1, 20, 512, 128), "float32", True, {"FLASH_HIP_VEC_MAX_N": "0"}),       # the same in the eight-wave layout
+]
+
+
+@pytest.mark.parametrize("case", RESUME_CASES, ids=str)
+def test_giving_up_and_resuming_in_every_persistent_kernel(fa, oracle, torch_gpu, monkeypatch, case):
+    """Eight workgroups (one per XCD) walk lists of five to ten items.  Overflowing peaks sit in the second
+    item of the first list, the last item of the second, in the middle of the third (two of them); the other
+    lists meet none.  Every head is compared: the items before the one that overflowed keep the first sweep's
+    result, that item and those behind it come from the second sweep."""
+    shape, dtype_name, ws, env = case
+    B, H, N, d = shape
+    dtype = getattr(torch_gpu, dtype_name)
+    rng = np.random.default_rng(H + N + d)
+    q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+    tile_q = 512 if (d <= 64 and N % 512 == 0 and env.get("FLASH_HIP_TALL") != "0" and dtype_name == "float16") else 256
+    nqt = N // tile_q
+    items = H * nqt
+    per_list = items // 8                      # items are dealt to the XCDs in contiguous ranges
+    assert items % 8 == 0 and per_list >= 5
+    hot_items = [1, 2 * per_list - 1, 2 * per_list + 2, 2 * per_list + 3]
+    for it in hot_items:
+        h, qt = divmod(it, nqt)
+        row = qt * tile_q + 17                 # a query row of that item; key 100 lies in a block nobody looks at
+        plant(q[:, h:h + 1], k[:, h:h + 1], row, 100, 40.0)
+    q, k, v = (oracle.round_f16(x) for x in (q, k, v))
+    with routing(fa, monkeypatch, FLASH_HIP_GRID=8, **env):
+        o = run_abi(fa, torch_gpu, q, k, v, fa.KernelType.mma_qreg_async, dtype, workspace=ws)
+    for h in range(H):
+        ref = oracle.attn_naive(*(x[:, h:h + 1] for x in (q, k, v)))[0, 0]
+        assert_close(o[0, h], ref, f"head {h} of {shape} {dtype_name} {env}")
+
+
 def test_nan_in_one_head_stays_there_and_the_kernel_returns(fa, oracle, torch_gpu):
     """A NaN in K poisons every query of its head (as it does in the plain formula); the first sweep stops at
     an item of that head, the second computes it again (NaN again) and goes on; every other head is untouched."""
