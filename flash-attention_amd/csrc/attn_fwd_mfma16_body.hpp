@@ -1251,6 +1251,10 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   auto staged_barrier = [&]() __attribute__((always_inline)) {
     if constexpr (KV32) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (the tile's LDS writes are this wave's own)
+    } else if constexpr ((kKnock & 512) != 0) {
+      // timing only: what waiting for the tiles staged in this very iteration costs (a ring staged one tile
+      // further ahead would wait like this)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kPiecesPerWave) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
