@@ -1258,7 +1258,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    // (1024: timing only, what meeting the other waves once per tile costs)
+    if constexpr ((kKnock & 1024) == 0) __syncthreads();
   };
   auto head_of = [&](uint32_t it) __attribute__((always_inline)) { return it / (uint32_t)p.nqt; };
   // (with fp32 K and V the eight-wave layout reads Q as fp32 too: all of a wave's Q lands in the score,
