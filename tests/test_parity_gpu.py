@@ -346,8 +346,8 @@ def test_both_wave_layouts_of_the_persistent_kernel(fa, oracle, torch_gpu, monke
                     outs.append(o)
         # same arithmetic per query row in both layouts (only the wave-wide decision to move a reference
         # can fall differently, which rounds the fp16 probabilities at another scale): the fp16 results
-        # agree to a rounding step of an output below 1 (2^-11), a quarter of the bar
-        assert np.abs(outs[0] - outs[2]).max() <= 5e-4, f"{shape}: the two layouts differ"
+        # agree to a rounding step of an output below 2 (2^-10), half of the bar
+        assert np.abs(outs[0] - outs[2]).max() <= 1e-3, f"{shape}: the two layouts differ"
 
 
 def test_tall_layout_of_the_persistent_d64_kernel(fa, oracle, torch_gpu, monkeypatch):
@@ -370,7 +370,7 @@ def test_tall_layout_of_the_persistent_d64_kernel(fa, oracle, torch_gpu, monkeyp
                     for bh in heads:
                         assert_close(o[bh], ref[bh], f"{shape} head {bh} tile_q {tile_q} {dtype}")
                     outs.append(o)
-        assert np.abs(outs[0] - outs[2]).max() <= 5e-4, f"{shape}: the two layouts differ"
+        assert np.abs(outs[0] - outs[2]).max() <= 1e-3, f"{shape}: the two layouts differ"
 
 
 # ---- full-size configurations: size-independent properties + sampled heads vs the oracle ----------
