@@ -1308,15 +1308,14 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   // in phases of at most 64 landing registers (the epilogue needs room of its own): phase ph covers
   // query blocks [ph * kQPerPhase, (ph + 1) * kQPerPhase) and is converted behind the output stores of
   // the same query blocks.
-  // (With fp32 K and V as well, the first phase is fetched a whole step earlier, at the item's last Q K^T
-  // product, into the registers of the score tile, K fragments and references that step no longer needs.)
-  constexpr int kQPhases = (QF32 && (kQ16 * kKS > 8 || (kWaves == 8 && D == 128))) ? 2 : 1;
-  // the early scheme described above (four-wave layout with fp32 K and V)
-  constexpr bool kQEarly = KV32 && kQ16 == 4;
+  // (fp16 K and V out of the conversion pass, fp32 Q; with fp32 K and V as well Q comes through converting
+  // loads instead, see fetch_q_direct.)
+  constexpr bool QLAND = QF32 && !KV32;
+  constexpr int kQPhases = (QLAND && (kQ16 * kKS > 8 || (kWaves == 8 && D == 128))) ? 2 : 1;
   constexpr int kQPerPhase = kQ16 / kQPhases;
-  u32x4 q_land[QF32 ? kQPerPhase : 1][QF32 ? kKS : 1][2];
+  u32x4 q_land[QLAND ? kQPerPhase : 1][QLAND ? kKS : 1][2];
   auto fetch_q32 = [&](uint32_t it, int ph) __attribute__((always_inline)) {
-    if constexpr (QF32) {
+    if constexpr (QLAND) {
       const uint32_t hd = head_of(it), qt = it - hd * (uint32_t)p.nqt;
       const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(
           (void*)((const char*)p.q + (size_t)hd * head_elems * 4u), 0, (uint32_t)(head_elems * 4u), 0x00020000);
@@ -1324,28 +1323,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       for (int q = 0; q < kQPerPhase; ++q) {
 #pragma unroll
         for (int ks = 0; ks < kKS; ++ks) {
-          if constexpr (KV32) {
-            // per-lane offsets of query block 0 only (four registers instead of sixteen): the block and
-            // the tile are a wave-uniform offset, which the range check does not see (whole tiles: every
-            // row exists; a chunk beyond d stays out of range through its per-lane part)
-            const uint32_t soff = __builtin_amdgcn_readfirstlane(
-                qt * q_tile_bytes + (uint32_t)((ph * kQPerPhase + q) * 16) * (uint32_t)d * kQElem);
-            // (the chunk's second half through the scalar offset as well: a per-lane `q_off + 16` would be one
-            // more register per k-step that lives through the kernel)
-            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
-            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff + 16u, 0);
-          } else {
-            const uint32_t soff = __builtin_amdgcn_readfirstlane(
-                qt * q_tile_bytes + (uint32_t)(ph * kQPerPhase + q) * q_block_bytes);
-            q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
-            q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff + 16u, 0);
-          }
+          const uint32_t soff = __builtin_amdgcn_readfirstlane(
+              qt * q_tile_bytes + (uint32_t)(ph * kQPerPhase + q) * q_block_bytes);
+          q_land[q][ks][0] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff, 0);
+          q_land[q][ks][1] = __builtin_amdgcn_raw_buffer_load_b128(q_rs, q_off[ks], soff + 16u, 0);
         }
       }
     }
   };
   auto convert_q32 = [&](int ph) __attribute__((always_inline)) {
-    if constexpr (QF32) {
+    if constexpr (QLAND) {
 #pragma unroll
       for (int q = 0; q < kQPerPhase; ++q) {
 #pragma unroll
@@ -1358,19 +1345,86 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     }
   };
 
+  // fp32 Q with fp32 K and V: two converting loads per fragment (see load_kv_f32_as_f16) deliver its eight
+  // fp16 values in two register pairs; all of a wave's Q lands in 4 * kQ16 * kKS vector registers (the score,
+  // probability and fragment registers are free between an item's last P V product and the next item's
+  // first scores) and moves to the Q registers when it has arrived.  No conversion on the vector ALU, one phase.  The compiler does not see the loads:
+  // q_arrived waits (counting the younger vector memory operations) before the pairs are read.
+  u32x2 q_pair[KV32 ? kQ16 : 1][KV32 ? kKS : 1][2];
+  auto kLandInAcc = [](int q) { return D == 128 && q >= kQ16 / 2; };
+  auto fetch_q_direct = [&](uint32_t it) __attribute__((always_inline)) {
+    if constexpr (KV32) {
+      const uint32_t hd = head_of(it), qt = it - hd * (uint32_t)p.nqt;
+      srd_t q_srd = make_srd((const char*)p.q + (size_t)hd * head_elems * 4u, head_bytes * 2u);
+      uint32_t soff[kQ16];
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) soff[q] = __builtin_amdgcn_readfirstlane(qt * q_tile_bytes + (uint32_t)q * q_block_bytes);
+      settle_scalars(q_srd, soff);
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+          // (half of the pairs land in accumulation registers: the Q registers themselves are free then)
+          if (kLandInAcc(q)) {
+            asm volatile(
+                "tbuffer_load_format_d16_xyzw %0, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen\n\t"
+                "tbuffer_load_format_d16_xyzw %1, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen offset:16"
+                : "=&a"(q_pair[q][ks][0]), "=&a"(q_pair[q][ks][1])
+                : "v"(q_off[ks]), "s"(q_srd), "s"(soff[q])
+                : "memory");
+          } else {
+            asm volatile(
+                "tbuffer_load_format_d16_xyzw %0, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen\n\t"
+                "tbuffer_load_format_d16_xyzw %1, %2, %3, %4 format:[BUF_DATA_FORMAT_32_32_32_32,BUF_NUM_FORMAT_FLOAT] offen offset:16"
+                : "=&v"(q_pair[q][ks][0]), "=&v"(q_pair[q][ks][1])
+                : "v"(q_off[ks]), "s"(q_srd), "s"(soff[q])
+                : "memory");
+          }
+        }
+      }
+    }
+  };
+  auto q_arrived = [&](auto younger_tag) __attribute__((always_inline)) {
+    if constexpr (KV32) {
+      constexpr int YOUNGER = decltype(younger_tag)::value;
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+          if (kLandInAcc(q)) {
+            asm volatile("s_waitcnt vmcnt(%2)" : "+a"(q_pair[q][ks][0]), "+a"(q_pair[q][ks][1]) : "n"(YOUNGER) : "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q_pair[q][ks][0]), "+v"(q_pair[q][ks][1]) : "n"(YOUNGER) : "memory");
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) {
+          const u32x4 w = {q_pair[q][ks][0][0], q_pair[q][ks][0][1], q_pair[q][ks][1][0], q_pair[q][ks][1][1]};
+          qf[q][ks] = __builtin_bit_cast(f16x8, w);
+          asm volatile("" : "+a"(qf[q][ks]));
+        }
+      }
+    }
+  };
+
   uint32_t item = start_item;
   // ---- cold start: Q, K tiles 0 and 1, V tile 0 of the first item --------------------------------------
   srd_t k_srd = kv_srd(p.k, head_of(item)), v_srd = kv_srd(p.v, head_of(item));
   settle_scalars(k_srd, v_srd);
-  if constexpr (QF32) {
+  if constexpr (KV32) {
+    fetch_q_direct(item);
+  } else if constexpr (QF32) {
     fetch_q32(item, 0);
   } else {
     fetch_q(item);
   }
   if constexpr (KV32) {
-    // K tiles 0 and 1 and V tile 0 in flight together with the first half of Q, through the same converting
-    // loads as in the loop; here they land in vector registers (the score and probability registers are
-    // still free) and go to LDS through ordinary stores.
+    // K tiles 0 and 1 and V tile 0 in flight together with Q, through the same converting loads as in the
+    // loop; here they land in vector registers (the score and probability registers are still free) and go
+    // to LDS through ordinary stores.
     u32x2 cold[3][kPiecesPerWave][2];
     auto cold_load = [&](int w, const srd_t srd, uint32_t toff) __attribute__((always_inline)) {
       const uint32_t soff = __builtin_amdgcn_readfirstlane(toff);
@@ -1396,24 +1450,17 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     cold_load(1, v_srd, 0u);
     cold_load(2, k_srd, tile_step);
     __builtin_amdgcn_sched_barrier(0);
-    convert_q32(0);
-    if constexpr (kQPhases > 1) fetch_q32(item, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    // the cold loads are older than the second half of Q: wait for everything but that
-    {
-      constexpr int kYounger = kQPhases > 1 ? 2 * kQPerPhase * kKS : 0;
 #pragma unroll
-      for (int w = 0; w < 3; ++w) {
+    for (int w = 0; w < 3; ++w) {
 #pragma unroll
-        for (int i = 0; i < kPiecesPerWave; ++i)
-          asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cold[w][i][0]), "+v"(cold[w][i][1]) : "n"(kYounger) : "memory");
-      }
+      for (int i = 0; i < kPiecesPerWave; ++i)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(cold[w][i][0]), "+v"(cold[w][i][1]) : : "memory");
     }
     cold_write(0, k_ring);
     cold_write(1, v_ring);
     cold_write(2, k_ring + kTileBytes);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (kQPhases > 1) convert_q32(1);
+    q_arrived(std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
   } else {
 #pragma unroll
@@ -1426,7 +1473,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   }
   const LaneAddr<D> la = make_lane_addr<D>(lane, k_ring, v_ring);
   if constexpr (KV32) {
-    // (converted above, between the cold K/V loads)
+    // (arrived above, with the cold K/V loads)
   } else if constexpr (QF32) {
     convert_q32(0);
     if constexpr (kQPhases > 1) {
@@ -1584,9 +1631,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       if constexpr (LAST) {
         // The item's last Q K^T product has been issued, Q is dead: fetch the next item's Q now.  The
         // loads have the last step, the last P V product and the output stores to land.
-        if constexpr (kQEarly) {
-          if (has_next) fetch_q32(next_item, 0);
-        } else if constexpr (!QF32) {
+        if constexpr (!QF32) {
           if (has_next) fetch_q(next_item);
         }
       }
@@ -1599,7 +1644,9 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
         if (has_next && !QF32) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQ16 * kKS) : "memory");
         } else if constexpr (KV32) {
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          // every fp32 tile load of this iteration has been waited for by the piece that wrote it to LDS: the
+          // barrier only needs those writes
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1665,16 +1712,33 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       drain_o(o);
       drain_lsum<D>(lsum);
     }
-    if constexpr (kQEarly) {
+    // fp32 K and V: the next item's Q goes out now, into the registers the last product has just left; its
+    // loads have the output scaling and stores to land
+    if constexpr (KV32) {
+      __builtin_amdgcn_sched_barrier(0);
       if (has_next) {
-        convert_q32(0);
-        if constexpr (kQPhases > 1) fetch_q32(next_item, 1);
+        fetch_q_direct(next_item);
+      } else {
+        // (a definition on this path too, without an instruction: otherwise the landing registers' last
+        // values stay alive around the whole item loop)
+#pragma unroll
+        for (int q = 0; q < kQ16; ++q) {
+#pragma unroll
+          for (int ks = 0; ks < kKS; ++ks) {
+            if (kLandInAcc(q)) {
+              asm volatile("" : "=a"(q_pair[q][ks][0]), "=a"(q_pair[q][ks][1]));
+            } else {
+              asm volatile("" : "=v"(q_pair[q][ks][0]), "=v"(q_pair[q][ks][1]));
+            }
+          }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     uint32_t worst = 0u;  // largest row sum of the wave as an integer: infinities and NaNs compare above every number
 #pragma unroll
     for (int q = 0; q < kQ16; ++q) {
-      if constexpr (QF32 && !kQEarly) {
+      if constexpr (QLAND) {
         if (q % kQPerPhase == 0) {
           // (the Q registers have been free since the item's last Q K^T product)
           if (q > 0 && has_next) convert_q32(q / kQPerPhase - 1);
@@ -1689,10 +1753,13 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
       const float inv = __builtin_amdgcn_rcpf(l);  // v_rcp_f32, 1 ulp
       const uint32_t qrow = qt * (uint32_t)kBr + (uint32_t)(wave * kRowsPerWave + q * 16 + n16);
       store_o_block<kDv16, TO, kOutAux>(o[q], inv, qrow, d, g, o_rs);
+      // (one query block at a time while the next item's Q is landing in vector registers: left alone the
+      // compiler reads all of O^T out of the accumulation registers first)
+      if constexpr (KV32) __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SPARSE) {
       // A probability beyond the fp16 range (a score more than 16 exp2 units above a reference that most
-      // steps no longer update) shows as an infinite row sum: the item is marked and computed again below.
+      // steps no longer update) shows as an infinite row sum: the flag makes the workgroup start again at this item.
       if (__builtin_expect(__builtin_amdgcn_ballot_w64(worst >= 0x7f800000u) != 0, 0)) {
         if (lane == 0) __hip_atomic_store(&overflowed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -1712,8 +1779,8 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
 #endif
     if (!has_next) break;
     // the Q loads are older than this item's output stores: wait for everything but those stores
-    if constexpr (kQEarly && kQPhases == 1) {
-      // (converted right behind the last P V product)
+    if constexpr (KV32) {
+      q_arrived(std::integral_constant<int, kQ16 * OutStores<TO>::per_block(kDv16)>{});
     } else if constexpr (QF32) {
       convert_q32(kQPhases - 1);
     } else {

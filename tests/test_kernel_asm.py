@@ -9,6 +9,8 @@ free to park their operands in the other register file; these checks read the de
     one reads a result that is not there yet);
   * no MFMA result is touched by anything but a chained MFMA before its result latency is over;
   * the main loops hold exactly the expected number of MFMAs per unrolled tile triple;
+  * the destinations of the converting loads of the fp32 routes (issued from inline asm, unknown to the
+    compiler as loads) are left alone until a wait for vector memory;
   * dynamic LDS stays within the 160 KiB of a CU.
 """
 import importlib.util
@@ -223,6 +225,40 @@ def test_lds_dma_base_register_is_set_and_used_undisturbed(asm_text):
                 assert "m0" not in ins[j].split(None, 1)[0], (name, ins[j])
                 j -= 1
             assert j >= 0 and i - j >= 2 and i - j <= 12, (name, ins[max(0, i - 6):i + 1])
+
+
+def _regs(text):
+    used = set()
+    for c, a, b in re.findall(r"\b([av])\[(\d+):(\d+)\]", text):
+        used.update((c, r) for r in range(int(a), int(b) + 1))
+    for c, a in re.findall(r"\b([av])(\d+)\b", text):
+        used.add((c, int(a)))
+    return used
+
+
+def test_converting_loads_land_undisturbed(asm_text):
+    """The fp32 routes load K, V and Q with typed buffer loads issued from inline asm, which the compiler
+    does not know to be loads: it is free to copy their destination registers right behind them, before the
+    data has arrived (it did, wherever it ran out of registers of the landing class).  Between every such
+    load and the next s_waitcnt that names vmcnt nothing may read or write its destination."""
+    pat = re.compile(r"tbuffer_load_format_d16_xyzw ([av])\[(\d+):(\d+)\]")
+    seen = 0
+    for name, lines in kernels(asm_text).items():
+        ins = [l for l in lines if not l.startswith(".LBB")]
+        for k, l in enumerate(ins):
+            m = pat.match(l)
+            if not m:
+                continue
+            seen += 1
+            dst = {(m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1)}
+            for t in range(k + 1, len(ins)):
+                x = ins[t]
+                if x.startswith("s_waitcnt") and "vmcnt" in x:
+                    break
+                assert not (_regs(x) & dst), (name, l, x)
+            else:
+                raise AssertionError((name, l, "no wait behind this load"))
+    assert seen >= 200   # the persistent and the one-item kernels of both head-dim tiles
 
 
 def test_no_mfma_reads_a_register_written_just_before_it(asm_text):
