@@ -151,6 +151,27 @@ def test_giving_up_and_resuming_in_every_persistent_kernel(fa, oracle, torch_gpu
         assert_close(o[0, h], ref, f"head {h} of {shape} {dtype_name} {env}")
 
 
+RAGGED = [(1, 3, 1000, 128), (2, 5, 1000, 64), (1, 2, 4000, 128), (1, 3, 450, 128)]
+
+
+@pytest.mark.parametrize("shape", RAGGED, ids=str)
+def test_one_item_kernels_follow_peaks_anywhere(fa, oracle, torch_gpu, shape):
+    """Ragged N runs one work item per workgroup, with the maximum taken in every step (a first pass that
+    looks at one tile in three, with a repeat on overflow, was built for these kernels too and measured
+    1.4 - 2.7 % slower).  The same planted scores as above: moderate peaks and large ones, fp16 and fp32 tensors."""
+    B, H, N, d = shape
+    assert not fa.launch_info(*shape).persistent
+    for gains, label in (((10.0, 11.0, 9.5), "moderate"), ((28.0, 50.0, 35.0), "large")):
+        rng = np.random.default_rng(N + d + 1)
+        q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+        # keys 100 and 150 lie in tiles 1 and 2, key 300 in tile 4: tiles that do not look when N > 320
+        for (row, key), gain in zip([(5, 100), (300, 150), (N - 41, 300)], gains):
+            plant(q, k, row, key, gain)
+        q, k, v = (oracle.round_f16(x) for x in (q, k, v))
+        for dtype in (torch_gpu.float16, torch_gpu.float32):
+            check_heads(fa, oracle, torch_gpu, q, k, v, dtype, f"{label} peaks, ragged {shape} {dtype}")
+
+
 def test_nan_in_one_head_stays_there_and_the_kernel_returns(fa, oracle, torch_gpu):
     """A NaN in K poisons every query of its head (as it does in the plain formula); the first sweep stops at
     an item of that head, the second computes it again (NaN again) and goes on; every other head is untouched."""
