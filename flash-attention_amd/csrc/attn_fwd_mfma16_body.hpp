@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
   const size_t head_elems = (size_t)N * (size_t)d;
   const uint32_t head_bytes = (uint32_t)(head_elems * 2);
   constexpr uint32_t kKVElem = KV32 ? 4u : 2u;
-  static_assert(!KV32 || (std::is_same<TO, float>::value && kQ16 <= 4),
+  static_assert(!KV32 || (std::is_same<TO, float>::value && (kQ16 <= 4 || D == 64)),
                 "fp32 K and V come with fp32 Q and fp32 O (four- and eight-wave layouts)");
   const uint32_t row_bytes = (uint32_t)d * kKVElem;
   const uint32_t tile_step = (uint32_t)kBc * row_bytes;

@@ -243,8 +243,10 @@ int launch_m16(const FwdParams& prm, uint32_t lds, hipStream_t stream) {
 // attention kernel; converting in the kernel costs every workgroup that reads a K/V tile 32 conversions
 // and twice the L2 -> LDS bytes.  Few readers per tile (N / 256 of them) favour the latter.  Measured
 // (tests/native/selftest benchf32, TFLOP/s in-kernel / pass): (4,96,N,128) 478 / 385 at N = 512, 680 / 617 at
-// 1024, 860 / 850 at 2048, 965 / 1020 at 4096; (16,32,N,64) 483 / 349 at 512, 518 / 580 at 1024 (there the
-// pass is followed by the 128-rows-per-wave layout, which the fp32 kernels do not have).
+// 1024, 860 / 850 at 2048, 965 / 1020 at 4096; (16,32,N,64) with 64 query rows per wave 483 / 349 at 512,
+// 518 / 580 at 1024.  Whole 512-row tiles of head dims up to 64 run 128 rows per wave in both routes, and
+// there the in-kernel route wins at every length (755 / 596 at N = 1024, 935 / 795 at 2048, 1050 / 952 at 4096,
+// 1055 / 1017 at 8192, 1102 / 1096 at 16384): see cast_copies.
 constexpr int64_t kVecDefaultMaxN128 = 2048;
 constexpr int64_t kVecDefaultMaxN64 = 768;
 
@@ -318,8 +320,21 @@ bool use_tall(const Switches& sw, int tile_d, int64_t N) { return tile_d == 64 &
 // fp32 Q, K, V, O with rows of a multiple of 8 elements: the same kernels with register staging (128-bit
 // fp32 loads, rounded to fp16 on their way into LDS), four waves x 64 query rows.  Whole query tiles run the
 // persistent kernel, ragged N one work item per workgroup.
+bool vec_tall(int tile_d, int64_t N);  // (below, with the other routing decisions)
 template <int D>
 int launch_m16_vec(const FwdParams& prm, uint32_t lds, bool persistent, hipStream_t stream) {
+  if constexpr (D == 64) {
+    if (persistent && vec_tall(D, prm.N)) {
+      // d <= 64, whole 512-row query tiles: 128 query rows per wave, so that every fp32 K/V tile is fetched
+      // by half as many workgroups (at d = 64 the in-kernel route is bound by those re-reads)
+      FwdParams tall = prm;
+      tall.nqt = (int)(prm.N / m16x::kBr);
+      tall.total_wg = prm.total_wg / (uint32_t)prm.nqt * (uint32_t)tall.nqt;
+      static AttrDone attr_done_t;
+      return launch_kernel(m16x::attn_fwd_kernel_m16p<64, float, true>, tall, (uint32_t)m16x::CfgP<64>::kLdsBytes,
+                           stream, attr_done_t, kPersistentGrid, (uint32_t)m16x::kThreads);
+    }
+  }
   if (persistent) {
     // (four waves x 64 query rows also at d = 128: the eight-wave layout has no registers left to land fp32
     // tiles in and measured 10-20 % slower here)
@@ -389,6 +404,8 @@ bool vec_persistent(int64_t N) {
   const Switches sw = switches();
   return N % kBr == 0 && N <= sw.persistent_max_n && sw.persistent;
 }
+// ... in the 128-rows-per-wave layout for whole 512-row tiles of head dims up to 64
+bool vec_tall(int tile_d, int64_t N) { return vec_persistent(N) && use_tall(switches(), tile_d, N); }
 
 // fp16 Q, K, V with 16-byte row chunks, O as fp16 or fp32
 template <typename TO>
@@ -464,6 +481,9 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
 int cast_copies(const Plan& plan, int64_t N) {
   const int64_t vec_max_n = switches().vec_max_n;
   if (!plan.fast || N <= (vec_max_n >= 0 ? vec_max_n : (plan.tile_d == 64 ? kVecDefaultMaxN64 : kVecDefaultMaxN128))) return 0;
+  // head dims up to 64 in whole 512-row query tiles: the 128-rows-per-wave kernel converts in place at every
+  // length (unless the switch says otherwise)
+  if (vec_max_n < 0 && vec_tall(plan.tile_d, N)) return 0;
   const Route route = pick_route(plan, N, true);
   return (route == kRouteTall || route == kRouteWide) ? 3 : 2;
 }
@@ -627,7 +647,8 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->tile_d = (uint32_t)plan.tile_d;
   // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
   const Route route = plan.fast ? pick_route(plan, N, entry == FLASH_ENTRY_F32_WS)
-                                : ((plan.vec && vec_persistent(N)) ? kRoutePersistent : kRouteItem);
+                                : ((plan.vec && vec_persistent(N)) ? (vec_tall(plan.tile_d, N) ? kRouteTall : kRoutePersistent)
+                                                                   : kRouteItem);
   const bool persistent = route != kRouteItem;
   out->lds_bytes = !persistent ? plan.lds
                                : (uint32_t)(plan.tile_d == 64 ? m16::CfgP<64>::kLdsBytes : m16::CfgP<128>::kLdsBytes);

@@ -147,11 +147,12 @@ int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
  * every sequence length (reference main.cpp:30-32, benchmarks/bench.py:34-36, flash/launch.cu:165-176; the
  * reference itself allocates per-call scratch for its non-register kernels, launch.cu:150-157).
  * Converting inside the attention kernel costs every workgroup that reads a K/V tile its conversion, so
- * beyond a sequence length where a tile has many readers (N > 2048; N > 768 for head dims up to 64) and
- * when d % 8 == 0, one streaming pass rounds K and V to fp16 (round-to-nearest-even, the rounding
+ * beyond a sequence length where a tile has many readers (N > 2048; N > 768 for head dims up to 64, except
+ * N % 512 == 0, which the 128-rows-per-wave kernel converts itself at every length) and when d % 8 == 0, one streaming pass rounds K and V to fp16 (round-to-nearest-even, the rounding
  * flash_fwd_f32 applies) into `workspace` once, and the fp16 kernels of flash_fwd_f16 run on those copies,
- * reading Q from the caller's fp32 tensor (rounded the same way on its way into the registers; the
- * 128-rows-per-wave layout takes Q from the pass as well) and writing O as fp32 straight from the
+ * reading Q from the caller's fp32 tensor (rounded the same way on its way into the registers; a layout
+ * that cannot, reachable through the routing switches only, takes Q from the pass as well) and writing O as
+ * fp32 straight from the
  * accumulators.  Same results as flash_fwd_f32 up to the order of fp32 additions.  Shorter sequences are
  * handled exactly as by flash_fwd_f32 and touch no workspace.
  * `workspace`: device memory, 16-byte aligned, at least flash_fwd_f32_workspace_bytes(...) bytes;
@@ -174,11 +175,10 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
  * and gives bit-identical results.
  * Limit: shapes whose workspace (flash_fwd_f32_workspace_bytes) exceeds the built-in buffer are rejected
  * with INVALID_ARGUMENT and a text naming both sizes; use flash_fwd_f32_ws for those.  The workspace holds
- * the fp16 copies of K and V (B*H*N*d <= 12 Mi elements fit), and of Q as well where the pass converts it
- * (head dims up to 64 with N % 512 == 0: 8 Mi elements).  Calls that need no workspace have no limit and
+ * the fp16 copies of K and V (B*H*N*d <= 12 Mi elements fit).  Calls that need no workspace have no limit and
  * behave like flash_fwd_f32: sequences short enough to be converted inside the attention kernel
- * (flash_fwd_f32_workspace_bytes returns 0), head dims that are not a multiple of 8, tensors off a 16-byte
- * boundary.
+ * (flash_fwd_f32_workspace_bytes returns 0: N <= 2048, N <= 768 or N % 512 == 0 for head dims up to 64), head
+ * dims that are not a multiple of 8, tensors off a 16-byte boundary.
  * All calls on one GPU share that GPU's buffer: calls that may overlap in time on one GPU (different
  * streams, different threads) race on it and must be serialised by the caller.  Nothing in the
  * buffer needs clearing between calls: every byte a call reads was written by the same call.
@@ -192,8 +192,9 @@ int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o,
                          float softmax_scale, int kernel_type, void* hip_stream);
 
 /* Workspace flash_fwd_f32_ws uses for this shape: the fp16 copies its conversion pass writes (two of
- * B*H*N*d elements, three for the 128-rows-per-wave layout), 0 when the call converts inside the attention
- * kernel (short sequences, d % 8 != 0), -1 (and an error text) when the shape or kernel type is rejected.
+ * B*H*N*d elements; three where a routing switch puts a layout that cannot read fp32 Q behind the pass), 0
+ * when the call converts inside the attention kernel (short sequences, whole 512-row tiles of head dims up
+ * to 64, d % 8 != 0), -1 (and an error text) when the shape or kernel type is rejected.
  * Does not touch the GPU. */
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type);
 

@@ -150,13 +150,17 @@ def test_null_pointer_and_errors_through_raw_abi(fa):
 
 
 def test_fp32_workspace_size_query(fa):
-    """No GPU needed: the fp16 copies the conversion pass writes (256-byte granules) -- K and V, and Q as
-    well for the 128-rows-per-wave layout; 0 for shapes that are converted inside the attention kernel
-    (rows without 16-byte chunks, sequences up to the register-staging limit); -1 with the reference's
+    """No GPU needed: the fp16 copies the conversion pass writes (256-byte granules) -- K and V (and Q as
+    well where a routing switch sends the 128-rows-per-wave layout behind the pass); 0 for shapes that are
+    converted inside the attention kernel (rows without 16-byte chunks, sequences up to the register-staging
+    limit, whole 512-row tiles of head dims up to 64); -1 with the reference's
     error text for shapes flash::forward rejects."""
     L = fa.lib()
     assert L.flash_fwd_f32_workspace_bytes(4, 96, 4096, 128, 11) == 2 * 4 * 96 * 4096 * 128 * 2
-    assert L.flash_fwd_f32_workspace_bytes(16, 32, 2048, 64, 11) == 3 * 16 * 32 * 2048 * 64 * 2
+    assert L.flash_fwd_f32_workspace_bytes(16, 32, 1280, 64, 11) == 2 * 16 * 32 * 1280 * 64 * 2
+    # whole 512-row query tiles of head dims up to 64 are converted inside the kernel at every length
+    assert L.flash_fwd_f32_workspace_bytes(16, 32, 2048, 64, 11) == 0
+    assert L.flash_fwd_f32_workspace_bytes(8, 32, 16384, 64, 11) == 0
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 2049, 8, 0) == 2 * ((2049 * 8 * 2 + 255) // 256 * 256)
     assert L.flash_fwd_f32_workspace_bytes(4, 96, 2048, 128, 11) == 0
     assert L.flash_fwd_f32_workspace_bytes(16, 32, 768, 64, 11) == 0

@@ -101,9 +101,10 @@ TUNED = {
 def test_tuned_main_loops_keep_operands_in_place(asm_text, frag):
     # three instantiations each: fp16 in/out, bfloat16 in/out, fp16 in with O written as fp32 (same loop
     # structure, different matrix-instruction mnemonics and epilogues); the four-wave kernels also exist
-    # with fp32 K and V staged through registers ("Lb1": the same steps plus loads, conversions and LDS writes)
+    # with fp32 K and V staged through registers ("Lb1": the same steps plus loads, conversions and LDS writes),
+    # and so does the 128-rows-per-wave kernel
     ks = {n: l for n, l in kernels(asm_text).items() if frag in n}
-    assert len(ks) == (4 if frag.startswith("3m16") else 3), list(ks)
+    assert len(ks) == (4 if frag.startswith("3m16") or frag.startswith("4m16x") else 3), list(ks)
     for name, lines in ks.items():
         per_step = TUNED[frag][0] // (2 * TUNED[frag][1])
         loop = main_loop(lines, TUNED[frag][0] - per_step)

@@ -116,7 +116,8 @@ RESUME_CASES = [
     ((1, 40, 1024, 64), "float16", False, {}),                                # four waves x 128 rows (512-row items)
     ((1, 20, 1024, 64), "float16", False, {"FLASH_HIP_TALL": "0"}),           # four waves x 64 rows, d = 64
     ((1, 20, 1024, 128), "float32", False, {}),                               # fp32 K/V converted in the kernel
-    ((1, 20, 1024, 64), "float32", False, {}),
+    ((1, 40, 1024, 64), "float32", False, {}),                                # the same, 128 rows per wave
+    ((1, 20, 1024, 64), "float32", False, {"FLASH_HIP_TALL": "0"}),           # the same, 64 rows per wave
     ((1, 20, 1024, 128), "float32", True, {"FLASH_HIP_VEC_MAX_N": "0"}),      # conversion pass, fp32 Q and O in the kernel
     ((1, 20, 512, 128), "float32", True, {"FLASH_HIP_VEC_MAX_N": "0"}),       # the same in the eight-wave layout
 ]
@@ -133,7 +134,7 @@ def test_giving_up_and_resuming_in_every_persistent_kernel(fa, oracle, torch_gpu
     dtype = getattr(torch_gpu, dtype_name)
     rng = np.random.default_rng(H + N + d)
     q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
-    tile_q = 512 if (d <= 64 and N % 512 == 0 and env.get("FLASH_HIP_TALL") != "0" and dtype_name == "float16") else 256
+    tile_q = 512 if (d <= 64 and N % 512 == 0 and env.get("FLASH_HIP_TALL") != "0") else 256
     nqt = N // tile_q
     items = H * nqt
     per_list = items // 8                      # items are dealt to the XCDs in contiguous ranges

@@ -30,9 +30,9 @@ def test_static_scratch_entry_matches_workspace_entry(fa, oracle):
     L = fa.lib()
     rng = np.random.default_rng(2024)
     # second call smaller than the first: stale contents of the shared buffer must not leak into it.  Both
-    # shapes are long enough to take the conversion pass (the route that uses the scratch: N > 2048, or
-    # N > 768 for head dims up to 64, where Q is converted by the pass as well)
-    for shape in ((1, 4, 4096, 128), (1, 3, 1024, 64)):
+    # shapes take the conversion pass (the route that uses the scratch: N > 2048, or N > 768 for head dims up
+    # to 64 unless N is a multiple of 512, which the kernel converts itself at every length)
+    for shape in ((1, 4, 4096, 128), (1, 3, 1280, 64)):
         B, H, N, d = shape
         host = [rng.standard_normal(shape).astype(np.float32) * np.float32(1.1) for _ in range(3)]
         q, k, v = (torch.from_numpy(x).to("cuda:0") for x in host)
@@ -65,9 +65,10 @@ def test_static_scratch_entry_rejects_what_does_not_fit(fa):
     msg = L.flash_hip_last_error().decode()
     assert "flash_fwd_f32_static" in msg and str(48 << 20) in msg and "flash_fwd_f32_ws" in msg
     assert L.flash_fwd_f32_workspace_bytes(1, 24, 4096, 128, 11) == 48 << 20
-    # Q, K and V copies for the 128-rows-per-wave layout: 8 Mi elements
-    assert L.flash_fwd_f32_workspace_bytes(1, 32, 4096, 64, 11) == 48 << 20
-    assert L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 33, 4096, 64, 0.1, 11, None) == -1
+    # head dims up to 64: whole 512-row tiles need no scratch at any length, other lengths beyond 768 two copies
+    assert L.flash_fwd_f32_workspace_bytes(1, 32, 4096, 64, 11) == 0
+    assert L.flash_fwd_f32_workspace_bytes(1, 60, 3840, 64, 11) == 2 * 60 * 3840 * 64 * 2
+    assert L.flash_fwd_f32_static(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 1, 60, 3840, 64, 0.1, 11, None) == -1
     # sequences short enough to be converted inside the attention kernel use no scratch and have no limit
     assert L.flash_fwd_f32_workspace_bytes(64, 96, 2048, 128, 11) == 0
     # errors of the plain entry points are kept
