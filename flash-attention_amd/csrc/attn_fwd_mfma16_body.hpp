@@ -1670,16 +1670,16 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     constexpr integral_constant<int, !SPARSE ? 3 : (kTrackMode == 1 ? FLASH_TRACK_LOOP : 0)> trk_loop{};
     constexpr integral_constant<int, !SPARSE ? 3 : 0> trk_rest{};
     tile_iter(integral_constant<int, 0>{}, no, no, yes, trk_first, 0);
-    // Every wave has passed the barrier that ends tile 0, hence finished the item before, output and verdict
+    // Every wave has passed the barrier that ends tile 0, hence finished the item before, output and overflow
     // included: all waves read the same value here.  The value is looked at one tile later, when it has
     // long arrived.  (Timing-only knock-out builds compute garbage on purpose and carry on.)
-    uint32_t verdict = 0u;
+    uint32_t seen = 0u;
     if constexpr (SPARSE && kKnock == 0) {
-      verdict = __hip_atomic_load(&overflowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      seen = __hip_atomic_load(&overflowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     tile_iter(integral_constant<int, 1>{}, no, no, no, trk_rest, 1);
     if constexpr (SPARSE && kKnock == 0) {
-      if (item != start_item && __builtin_expect(__builtin_amdgcn_readfirstlane(verdict) != 0u, 0)) {
+      if (item != start_item && __builtin_expect(__builtin_amdgcn_readfirstlane(seen) != 0u, 0)) {
         sweep_gave_up = true;
         break;
       }
@@ -1814,7 +1814,7 @@ __global__ __launch_bounds__(kThreads, 1) void attn_fwd_kernel_m16p(const FwdPar
     const bool marked =
         __builtin_amdgcn_readfirstlane(__hip_atomic_load(&overflowed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0u;
     // a sweep that gave up was one item past the one that overflowed; one that reached the end of its list
-    // has the verdict on its last item still to read
+    // has the mark of its last item still to read
     if (__builtin_expect(kKnock == 0 && (sweep_gave_up || marked), 0)) {
       sweep(std::false_type{}, sweep_gave_up ? sweep_end_item - wgs_on_xcd : sweep_end_item);
     }
