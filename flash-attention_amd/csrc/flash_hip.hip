@@ -336,8 +336,9 @@ int launch_m16_vec(const FwdParams& prm, uint32_t lds, bool persistent, hipStrea
     }
   }
   if (persistent) {
-    // (four waves x 64 query rows also at d = 128: the eight-wave layout has no registers left to land fp32
-    // tiles in and measured 10-20 % slower here)
+    // (four waves x 64 query rows also at d = 128: the eight-wave layout measured 10-20 % slower here while
+    // the tiles were converted on the vector ALU, and with the converting loads +0.7 % at N = 1024, +0.5 % at
+    // 2048 and -5 % at 512)
     static AttrDone attr_done_p;
     return launch_kernel(m16::attn_fwd_kernel_m16p<D, float, true>, prm, (uint32_t)m16::CfgP<D>::kLdsBytes, stream,
                          attr_done_p, kPersistentGrid, (uint32_t)m16::kThreads);
