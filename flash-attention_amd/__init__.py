@@ -154,8 +154,8 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
 
     Q, K, V: 4-D ``[B, H, N, d]`` tensors on a HIP device, fp16 (native), bf16 (same kernels with
     bfloat16 matrix instructions, d a multiple of 8) or fp32 (the reference's
-    dtype; rounded to fp16 by one conversion pass into per-call scratch, or inside the kernel when
-    d is not a multiple of 8; result returned as fp32).  Returns a new tensor O of
+    dtype; rounded to fp16 inside the kernel or by one conversion pass into per-call scratch, which
+    also pads rows to 16-byte chunks when d is not a multiple of 8; result returned as fp32).  Returns a new tensor O of
     the shape and dtype of Q.  Like the reference (flash/launch.cu:320-321) the call blocks until
     the kernel has finished unless ``sync=False``.
     """
@@ -183,7 +183,7 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
             fn = lib().flash_fwd_f16 if Q.dtype == torch.float16 else lib().flash_fwd_bf16
             rc = fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), out.data_ptr(), B, H, N, d, scale, int(kernel_type), sp)
         else:
-            # scratch for the fp16 copies of Q, K, V (the reference allocates per-call scratch too,
+            # scratch for the fp16 (or padded) copies of Q, K, V (the reference allocates per-call scratch too,
             # flash/launch.cu:150-157); torch's allocator re-issues the block in stream order
             # (a rejected shape reports -1 here; the call below then returns the matching status)
             ws_bytes = max(0, lib().flash_fwd_f32_workspace_bytes(B, H, N, d, int(kernel_type)))

@@ -476,6 +476,36 @@ int forward(const void* q, const void* k, const void* v, void* o, int64_t B, int
   return plan.tile_d == 64 ? launch<64, T, false>(prm, plan.lds, stream) : launch<128, T, false>(prm, plan.lds, stream);
 }
 
+// Head dims that are not a multiple of 8, fp32 callers with a workspace: the rows are copied into rows of
+// the next multiple of 8 elements (zero-filled) and the 16x16x32 kernels run on the copies (cast_f16.hpp:
+// pad_rows_kernel, unpad_rows_kernel).  `plan` is the plan of the padded shape.
+struct PadPlan {
+  int64_t d_pad;
+  Plan plan;
+  Route route;
+  bool q_f32;       // the route's kernel reads Q as fp32 (four-wave layouts), else as fp16
+  int64_t each;     // bytes of one padded fp16 tensor (256-byte granules)
+  int64_t need;     // workspace bytes: K, V (fp16), Q (room for fp32), O (fp32)
+};
+// Two more launches and a trip of every tensor through HBM: worth it from a few GFLOP of attention on
+// (below that a call is launch overhead either way, and the one-kernel element-staging route stays).
+constexpr double kPadMinFlops = 2e9;
+bool make_pad_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, PadPlan* pp) {
+  if (d % 8 == 0) return false;
+  if (4.0 * (double)B * (double)H * (double)N * (double)N * (double)d < kPadMinFlops) return false;
+  pp->d_pad = (d + 7) / 8 * 8;
+  char keep[sizeof(g_err)];
+  memcpy(keep, g_err, sizeof(g_err));  // a shape the padded plan rejects is no error: it stays on element staging
+  const int rc = make_plan(B, H, N, pp->d_pad, kernel_type, true, &pp->plan);
+  memcpy(g_err, keep, sizeof(g_err));
+  if (rc != FLASH_HIP_OK || !pp->plan.fast) return false;
+  pp->route = pick_route(pp->plan, N, true);
+  pp->q_f32 = pp->route == kRouteItem || pp->route == kRoutePersistent;
+  pp->each = ws_tensor_bytes(B, H, N, pp->d_pad);
+  pp->need = 6 * pp->each;  // K, V: one each; Q: two (fp32); O: two (fp32)
+  return true;
+}
+
 // fp16 copies the conversion pass of flash_fwd_f32_ws writes for this shape: none when the call converts
 // inside the attention kernel (rows without 16-byte chunks, sequences up to the register-staging limit),
 // K and V, or Q as well for the wave layouts that cannot read it as fp32.
@@ -498,8 +528,48 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
   Plan plan;
   int rc = make_plan(B, H, N, d, kernel_type, true, &plan);
   if (rc != FLASH_HIP_OK) return rc;
-  // rows without 16-byte chunks, a sequence short enough for the register-staged kernel, no workspace, or
-  // tensors that do not start on a 16-byte boundary: convert while staging
+  hipStream_t stream = (hipStream_t)hip_stream;
+  PadPlan pp;
+  if (!plan.fast && workspace && make_pad_plan(B, H, N, d, kernel_type, &pp)) {
+    // rows without 16-byte chunks: pad into the workspace, run the fast kernels there, copy O out
+    // (element loads and stores on the caller's side: any alignment of q, k, v, o will do)
+    if ((rc = check_scale(softmax_scale)) != FLASH_HIP_OK) return rc;
+    if (!q || !k || !v || !o) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "null tensor pointer");
+    if (workspace_bytes < pp.need)
+      return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace of %lld bytes is too small: %lld needed",
+                  (long long)workspace_bytes, (long long)pp.need);
+    if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
+    char* ws = (char*)workspace;
+    PadParams pad{};
+    pad.src[0] = (const float*)k;
+    pad.src[1] = (const float*)v;
+    pad.src[2] = (const float*)q;
+    pad.dst[0] = ws;
+    pad.dst[1] = ws + pp.each;
+    pad.dst[2] = ws + 2 * pp.each;
+    float* o_pad = (float*)(ws + 4 * pp.each);
+    pad.rows = (uint64_t)(B * H * N);
+    pad.d = (uint32_t)d;
+    pad.d_pad = (uint32_t)pp.d_pad;
+    pad.f32_mask = pp.q_f32 ? 4u : 0u;
+    const uint64_t blocks = (pad.rows + kPadRowsPerBlock - 1) / kPadRowsPerBlock;
+    const uint32_t gx = (uint32_t)(blocks < 4096 ? blocks : 4096);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(gx, kCastTensors), dim3(kCastThreads), 0, stream, pad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "padding kernel launch failed: %s", hipGetErrorString(e));
+    const FwdParams prm =
+        make_params(pad.dst[2], pad.dst[0], pad.dst[1], o_pad, B, H, N, pp.d_pad, softmax_scale, pp.plan, false);
+    if ((rc = launch_fast<float>(prm, pp.plan, pp.route, stream)) != FLASH_HIP_OK) return rc;
+    UnpadParams up{o_pad, (float*)o, pad.rows, pad.d, pad.d_pad};
+    const uint64_t groups = (pad.rows + 15) / 16;  // 16 rows per workgroup and trip
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3((uint32_t)(groups < 8192 ? groups : 8192)), dim3(kCastThreads), 0, stream,
+                       up);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(FLASH_HIP_ERR_RUNTIME, "output copy kernel launch failed: %s", hipGetErrorString(e));
+    return FLASH_HIP_OK;
+  }
+  // a sequence short enough for the register-staged kernel, no workspace, or tensors that do not start on a
+  // 16-byte boundary: convert while staging
   const int n_cast = cast_copies(plan, N);
   if (n_cast == 0 || !workspace || !aligned16(q, k, v, o))
     return forward<float>(q, k, v, o, B, H, N, d, softmax_scale, kernel_type, hip_stream);
@@ -510,7 +580,6 @@ int forward_f32_scratch(const void* q, const void* k, const void* v, void* o, in
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace of %lld bytes is too small: %lld needed",
                 (long long)workspace_bytes, (long long)(n_cast * each));
   if ((uintptr_t)workspace % 16 != 0) return fail(FLASH_HIP_ERR_INVALID_ARGUMENT, "workspace must be 16-byte aligned");
-  hipStream_t stream = (hipStream_t)hip_stream;
   // K and V, which every query tile of a head re-reads; Q is read by one workgroup per row and the
   // attention kernels take it from the caller's fp32 tensor (m16::kQFromF32), except in the
   // 128-rows-per-wave and eight-wave layouts.  The workspace keeps its three-slot layout (K, V, then Q if converted).
@@ -590,6 +659,8 @@ int flash_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type) {
   Plan plan;
   if (make_plan(B, H, N, d, kernel_type, true, &plan) != FLASH_HIP_OK) return -1;
+  PadPlan pp;
+  if (!plan.fast) return make_pad_plan(B, H, N, d, kernel_type, &pp) ? pp.need : 0;
   return (int64_t)cast_copies(plan, N) * ws_tensor_bytes(B, H, N, d);
 }
 
@@ -605,7 +676,12 @@ int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o, i
   if (rc != FLASH_HIP_OK) return rc;
   // what this call will really put into the buffer: nothing when it converts inside the attention kernel
   // (tensors off a 16-byte boundary included), else the two or three copies of the conversion pass
-  const int64_t need = aligned16(q, k, v, o) ? (int64_t)cast_copies(plan, N) * ws_tensor_bytes(B, H, N, d) : 0;
+  // (or the padded copies of rows without 16-byte chunks, whatever the alignment)
+  PadPlan pp;
+  int64_t need = !plan.fast ? (make_pad_plan(B, H, N, d, kernel_type, &pp) ? pp.need : 0)
+                            : (aligned16(q, k, v, o) ? (int64_t)cast_copies(plan, N) * ws_tensor_bytes(B, H, N, d) : 0);
+  // such rows have a kernel that needs no scratch (element staging): shapes too large to pad here take it
+  if (!plan.fast && need > kStaticScratchBytes) need = 0;
   if (need > kStaticScratchBytes)
     return fail(FLASH_HIP_ERR_INVALID_ARGUMENT,
                 "flash_fwd_f32_static: this shape needs %lld bytes of scratch, the built-in buffer holds %lld; "
@@ -632,14 +708,19 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   // fp32 callers whose call converts inside the attention kernel (no workspace, or a sequence up to the
   // register-staging limit) are described as flash_fwd_f32 launches them
   bool f32_in_kernel = entry == FLASH_ENTRY_F32;
+  PadPlan pp;
+  bool padded = false;
   if (entry == FLASH_ENTRY_F32_WS) {
     Plan probe;
     int prc = make_plan(B, H, N, d, kernel_type, true, &probe);
     if (prc != FLASH_HIP_OK) return prc;
-    f32_in_kernel = cast_copies(probe, N) == 0;
+    // rows without 16-byte chunks are padded into the workspace and run the fp16 kernels there
+    padded = !probe.fast && make_pad_plan(B, H, N, d, kernel_type, &pp);
+    f32_in_kernel = !padded && cast_copies(probe, N) == 0;
   }
   int rc = make_plan(B, H, N, d, kernel_type, !f32_in_kernel, &plan);
   if (rc != FLASH_HIP_OK) return rc;
+  if (padded) plan = pp.plan;
   if (entry == FLASH_ENTRY_BF16 && !plan.fast)
     return fail(FLASH_HIP_ERR_UNSUPPORTED_DIM, "bfloat16 tensors need a head dim that is a multiple of 8 (got %lld)",
                 (long long)d);
@@ -675,7 +756,7 @@ const char* flash_kernel_type_name(int kernel_type) {
 
 const char* flash_hip_last_error(void) { return g_err; }
 
-int flash_hip_version(void) { return 300; }
+int flash_hip_version(void) { return 310; }
 
 int flash_hip_reload_switches(void) {
   publish_switches();

@@ -74,7 +74,7 @@ typedef struct flash_launch_info {
   uint32_t staging;      /* how K/V tiles reach LDS: 0 = element loads through registers (any head dim, any
                             alignment), 1 = fp32 tensors through registers, rounded to fp16 on the way by converting loads
                             (fp32 tensors, d % 8 == 0), 2 = direct global->LDS loads (buffer_load ... lds;
-                            fp16 / bfloat16 tensors, and fp32 tensors behind the conversion pass) */
+                            fp16 / bfloat16 tensors, and fp32 tensors behind the conversion or padding pass) */
   uint32_t aligned_rows; /* 1 when d % 8 == 0 (128-bit row chunks usable), else 0 */
   uint32_t persistent;   /* 1: the work items (grid_x * grid_y * grid_z of them) are walked by a persistent
                             kernel launched as a 1-D grid of min(items, compute units rounded down to a
@@ -96,7 +96,8 @@ typedef enum flash_hip_entry {
                              attention kernel, four waves x 64 query rows */
   FLASH_ENTRY_F32_WS = 3  /* flash_fwd_f32_ws with a workspace, flash_fwd_f32_static: as FLASH_ENTRY_F32 for
                              sequences up to 2048 (768 for head dims up to 64), beyond that the conversion pass
-                             and the fp16 kernels with fp32 output */
+                             and the fp16 kernels with fp32 output; for d % 8 != 0 (from about 2 GFLOP on) the
+                             launch on the padded copies: tile_d from the padded head dim, staging 2 */
 } flash_hip_entry;
 
 /*
@@ -155,6 +156,14 @@ int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
  * fp32 straight from the
  * accumulators.  Same results as flash_fwd_f32 up to the order of fp32 additions.  Shorter sequences are
  * handled exactly as by flash_fwd_f32 and touch no workspace.
+ * Head dims that are not a multiple of 8 (the reference's runner tests 50 and 69, main.cpp:169-183) have rows
+ * without 16-byte chunks, which flash_fwd_f32 stages element by element at about a sixth of the fast kernels'
+ * rate.  With a workspace, and from about 2 GFLOP of attention on (4*B*H*N*N*d; below that the one-kernel
+ * route stays), one pass copies Q, K and V into rows of the next multiple of 8 elements, zero-filled (K and V
+ * rounded to fp16 as above; Q as well, or kept as fp32 for the wave layouts that read it so), the kernels of
+ * flash_fwd_f16 run on the copies with the caller's softmax_scale, and one more pass copies the first d
+ * columns of their fp32 output into `o`.  The caller's tensors are read and written element by element on
+ * this route and need no 16-byte alignment.  Measured at (4,96,4096,69): 576 against 187 TFLOP/s.
  * `workspace`: device memory, 16-byte aligned, at least flash_fwd_f32_workspace_bytes(...) bytes;
  * its contents are scratch and must not be touched until the work enqueued by this call has finished.
  * A NULL workspace, or a shape for which flash_fwd_f32_workspace_bytes returns 0, makes the call
@@ -177,8 +186,9 @@ int flash_fwd_f32_ws(const void* q, const void* k, const void* v, void* o,
  * with INVALID_ARGUMENT and a text naming both sizes; use flash_fwd_f32_ws for those.  The workspace holds
  * the fp16 copies of K and V (B*H*N*d <= 12 Mi elements fit).  Calls that need no workspace have no limit and
  * behave like flash_fwd_f32: sequences short enough to be converted inside the attention kernel
- * (flash_fwd_f32_workspace_bytes returns 0: N <= 2048, N <= 768 or N % 512 == 0 for head dims up to 64), head
- * dims that are not a multiple of 8, tensors off a 16-byte boundary.
+ * (flash_fwd_f32_workspace_bytes returns 0: N <= 2048, N <= 768 or N % 512 == 0 for head dims up to 64),
+ * tensors off a 16-byte boundary.  Head dims that are not a multiple of 8 use the buffer for their padded
+ * copies while those fit and take the element-staging kernel (no scratch) beyond, so they are never refused.
  * All calls on one GPU share that GPU's buffer: calls that may overlap in time on one GPU (different
  * streams, different threads) race on it and must be serialised by the caller.  Nothing in the
  * buffer needs clearing between calls: every byte a call reads was written by the same call.
@@ -194,7 +204,9 @@ int flash_fwd_f32_static(const void* q, const void* k, const void* v, void* o,
 /* Workspace flash_fwd_f32_ws uses for this shape: the fp16 copies its conversion pass writes (two of
  * B*H*N*d elements; three where a routing switch puts a layout that cannot read fp32 Q behind the pass), 0
  * when the call converts inside the attention kernel (short sequences, whole 512-row tiles of head dims up
- * to 64, d % 8 != 0), -1 (and an error text) when the shape or kernel type is rejected.
+ * to 64, small shapes with d % 8 != 0), -1 (and an error text) when the shape or kernel type is rejected.
+ * For d % 8 != 0 from about 2 GFLOP on: six fp16 tensors of the shape padded to d_pad = the next multiple
+ * of 8 (K, V as fp16, room for Q as fp32, the padded fp32 output), each rounded up to 256 bytes.
  * Does not touch the GPU. */
 int64_t flash_fwd_f32_workspace_bytes(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type);
 
@@ -219,7 +231,8 @@ const char* flash_kernel_type_name(int kernel_type);
  * failing call on the same thread. */
 const char* flash_hip_last_error(void);
 
-/* Library version, major*10000 + minor*100 + patch.  300: flash_launch_info unchanged since 200 (which
+/* Library version, major*10000 + minor*100 + patch.  310 (padded route for d % 8 != 0 behind
+ * flash_fwd_f32_ws; no interface change); flash_launch_info unchanged since 200 (which
  * appended `persistent`: callers built against 100 must be recompiled, the query functions write the
  * whole structure). */
 int flash_hip_version(void);

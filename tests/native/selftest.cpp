@@ -192,7 +192,7 @@ static int bench_f32(int64_t B, int64_t H, int64_t N, int64_t d, int reps) {
     fill_normal(x);
     HIP_CHECK(hipMemcpy(p, x.data(), n * 4, hipMemcpyHostToDevice));
   }
-  const int kt = FLASH_KT_MMA_QREG_ASYNC;
+  const int kt = d % 4 == 0 ? FLASH_KT_MMA_QREG_ASYNC : FLASH_KT_NAIVE1D;  // the async type needs d % 4 == 0
   const int64_t ws_bytes = flash_fwd_f32_workspace_bytes(B, H, N, d, kt);
   if (ws_bytes > 0) HIP_CHECK(hipMalloc(&ws, (size_t)ws_bytes));
   const float scale = 1.0f / std::sqrt((float)d);
@@ -388,7 +388,9 @@ int main(int argc, char** argv) {
                           {2, 4, 256, 64}, {2, 3, 300, 128}, {1, 2, 1024, 128}, {3, 2, 577, 64}, {1, 2, 257, 96},
                           {1, 1, 1, 8},    {1, 3, 129, 40},  {2, 2, 511, 120},
                           // whole-tile shapes with item counts that split unevenly over XCDs and workgroups
-                          {3, 7, 512, 64}, {5, 13, 1280, 128}, {1, 5, 256, 128}};
+                          {3, 7, 512, 64}, {5, 13, 1280, 128}, {1, 5, 256, 128},
+                          // rows without 16-byte chunks, enough work for the padded route of flash_fwd_f32_ws
+                          {2, 4, 1024, 69}, {1, 12, 1000, 50}};
   bool all = true;
   for (const Shape& s : shapes) {
     printf("shape (%lld,%lld,%lld,%lld)\n", (long long)s.B, (long long)s.H, (long long)s.N, (long long)s.d);
@@ -402,7 +404,7 @@ int main(int argc, char** argv) {
     all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, 2);
   }
   printf("forced rescale (spiked keys)\n");
-  const Shape spiked[] = {{1, 2, 640, 128}, {2, 2, 1000, 64}, {1, 1, 2048, 128}, {1, 2, 333, 72}};
+  const Shape spiked[] = {{1, 2, 640, 128}, {2, 2, 1000, 64}, {1, 1, 2048, 128}, {1, 2, 333, 72}, {2, 4, 1024, 68}};
   for (const Shape& s : spiked) {
     all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_MMA_QREG_ASYNC, 0, 6);
     all &= run_shape(s.B, s.H, s.N, s.d, FLASH_KT_NAIVE1D, 1, 6);

@@ -167,6 +167,15 @@ def test_fp32_workspace_size_query(fa):
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 3, 8, 0) == 0
     assert L.flash_fwd_f32_workspace_bytes(5, 12, 53, 69, 0) == 0
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 50, 9) == 0
+    # rows without 16-byte chunks, from a few GFLOP on: padded copies of K, V (fp16), Q (room for fp32) and
+    # a padded fp32 output, i.e. six fp16 tensors of the padded shape
+    assert L.flash_fwd_f32_workspace_bytes(4, 96, 1024, 69, 0) == 6 * 4 * 96 * 1024 * 72 * 2
+    assert L.flash_fwd_f32_workspace_bytes(4, 96, 1024, 50, 9) == 6 * 4 * 96 * 1024 * 56 * 2
+    assert L.flash_fwd_f32_workspace_bytes(1, 1, 1024, 50, 9) == 0      # 0.2 GFLOP: one element-staging kernel
+    info = fa.launch_info(4, 96, 1024, 100, entry=fa.ENTRY_F32_WS)
+    assert info.staging == 2 and not info.aligned_rows and info.tile_size == (64, 256, 128) and info.persistent
+    info = fa.launch_info(4, 96, 1024, 100, entry=fa.ENTRY_F32)
+    assert info.staging == 0 and not info.persistent
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 50, 11) == -1
     assert b"multiple of 4" in L.flash_hip_last_error()
     assert L.flash_fwd_f32_workspace_bytes(1, 1, 64, 256, 11) == -1

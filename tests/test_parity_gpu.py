@@ -37,7 +37,8 @@ def run_abi(fa, torch, q, k, v, kt, dtype, workspace=False):
         assert dtype == torch.float32
         nbytes = L.flash_fwd_f32_workspace_bytes(B, H, N, d, int(kt))
         each = (B * H * N * d * 2 + 255) // 256 * 256     # one fp16 copy; 0, 2 or 3 of them by route
-        assert nbytes in ((0, 2 * each, 3 * each) if d % 8 == 0 else (0,)), nbytes
+        pad = (B * H * N * ((d + 7) // 8 * 8) * 2 + 255) // 256 * 256   # rows padded to 16-byte chunks
+        assert nbytes in ((0, 2 * each, 3 * each) if d % 8 == 0 else (0, 6 * pad)), nbytes
         ws = torch.full((max(nbytes, 1),), 0xFF, dtype=torch.uint8, device="cuda:0")
         rc = L.flash_fwd_f32_ws(tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out.data_ptr(), B, H, N, d,
                                 1.0 / np.sqrt(d), int(kt), ws.data_ptr() if nbytes else None, nbytes, stream)
