@@ -499,7 +499,9 @@ bool make_pad_plan(int64_t B, int64_t H, int64_t N, int64_t d, int kernel_type, 
   const int rc = make_plan(B, H, N, pp->d_pad, kernel_type, true, &pp->plan);
   memcpy(g_err, keep, sizeof(g_err));
   if (rc != FLASH_HIP_OK || !pp->plan.fast) return false;
-  pp->route = pick_route(pp->plan, N, true);
+  // routed like fp16 tensors: Q is copied anyway, and an fp16 copy for the eight-wave layout is cheaper than
+  // an fp32 one for the four-wave layout that pick_route prefers for fp32 callers beyond N = 512
+  pp->route = pick_route(pp->plan, N, false);
   pp->q_f32 = pp->route == kRouteItem || pp->route == kRoutePersistent;
   pp->each = ws_tensor_bytes(B, H, N, pp->d_pad);
   pp->need = 6 * pp->each;  // K, V: one each; Q: two (fp32); O: two (fp32)
@@ -728,7 +730,8 @@ int flash_fwd_query_entry(int64_t B, int64_t H, int64_t N, int64_t d, int kernel
   out->tile_q = kBr;  // 512 for the 128-rows-per-wave layout, set below
   out->tile_d = (uint32_t)plan.tile_d;
   // whole-tile fp16 shapes run on the persistent kernel with four-slot rings
-  const Route route = plan.fast ? pick_route(plan, N, entry == FLASH_ENTRY_F32_WS)
+  const Route route = padded      ? pp.route
+                      : plan.fast ? pick_route(plan, N, entry == FLASH_ENTRY_F32_WS)
                                 : ((plan.vec && vec_persistent(N)) ? (vec_tall(plan.tile_d, N) ? kRouteTall : kRoutePersistent)
                                                                    : kRouteItem);
   const bool persistent = route != kRouteItem;

@@ -160,10 +160,11 @@ int flash_fwd_f32(const void* q, const void* k, const void* v, void* o,
  * without 16-byte chunks, which flash_fwd_f32 stages element by element at about a sixth of the fast kernels'
  * rate.  With a workspace, and from about 2 GFLOP of attention on (4*B*H*N*N*d; below that the one-kernel
  * route stays), one pass copies Q, K and V into rows of the next multiple of 8 elements, zero-filled (K and V
- * rounded to fp16 as above; Q as well, or kept as fp32 for the wave layouts that read it so), the kernels of
- * flash_fwd_f16 run on the copies with the caller's softmax_scale, and one more pass copies the first d
- * columns of their fp32 output into `o`.  The caller's tensors are read and written element by element on
- * this route and need no 16-byte alignment.  Measured at (4,96,4096,69): 576 against 187 TFLOP/s.
+ * rounded to fp16 as above; Q as well, or kept as fp32 for the one wave layout that reads it so), the kernels of
+ * flash_fwd_f16 run on the copies (routed as for fp16 tensors) with the caller's softmax_scale, and one more
+ * pass copies the first d columns of their fp32 output into `o`.  The caller's tensors are read and written
+ * element by element on this route and need no 16-byte alignment.  Measured at (4,96,4096,69): 630 against
+ * 187 TFLOP/s.
  * `workspace`: device memory, 16-byte aligned, at least flash_fwd_f32_workspace_bytes(...) bytes;
  * its contents are scratch and must not be touched until the work enqueued by this call has finished.
  * A NULL workspace, or a shape for which flash_fwd_f32_workspace_bytes returns 0, makes the call

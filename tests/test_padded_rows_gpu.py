@@ -37,11 +37,11 @@ def call_ws(fa, torch, tq, tk, tv, out, shape, kt, need=None):
 
 # shape, kernel type, (waves, query rows per tile, persistent) of the padded launch
 CASES = [
-    ((2, 8, 1024, 69), 0, (4, 256, 1)),    # d_pad 72 in the 128 tile; N > 512: four waves, Q read as fp32
-    ((4, 8, 512, 100), 11, (8, 256, 1)),   # d_pad 104; N = 512: eight waves, Q from an fp16 copy
+    ((2, 8, 1024, 69), 0, (8, 256, 1)),    # d_pad 72 in the 128 tile: eight waves, Q from an fp16 copy
+    ((4, 8, 512, 100), 11, (8, 256, 1)),   # d_pad 104
     ((1, 16, 1000, 50), 9, (4, 256, 0)),   # d_pad 56 in the 64 tile; ragged N: one item per workgroup
     ((2, 8, 1024, 52), 11, (4, 512, 1)),   # d_pad 56; whole 512-row tiles: 128 rows per wave
-    ((4, 8, 768, 36), 11, (4, 256, 1)),    # d_pad 40; 256-row tiles, four waves x 64 rows
+    ((4, 8, 768, 36), 11, (4, 256, 1)),    # d_pad 40; 256-row tiles, four waves x 64 rows, Q read as fp32
     ((1, 3, 4001, 127), 0, (4, 256, 0)),   # d_pad 128, one padding column, ragged N
 ]
 
