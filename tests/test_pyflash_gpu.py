@@ -53,3 +53,22 @@ def test_runner_correctness_suite(fa):
     out = subprocess.run([fa.RUNNER_PATH], capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
     assert "Test failed" not in out.stdout and out.stdout.count("Test passed") >= 50
+
+
+def test_odd_head_dim_through_the_operator_takes_the_padded_route(fa, oracle, pyflash):
+    """fp32 tensors with d = 69 (a head dim of the reference's runner, main.cpp:177-183) and enough work:
+    flash::forward sizes its scratch with flash_fwd_f32_workspace_bytes, so the operator and the Python
+    wrapper run the padded route (rows copied to 16-byte chunks, the fast kernels, output copied out)."""
+    import torch
+
+    shape = (2, 8, 1024, 69)
+    assert fa.lib().flash_fwd_f32_workspace_bytes(*shape, 0) > 0
+    assert fa.launch_info(*shape, kernel_type=0, entry=fa.ENTRY_F32_WS).staging == 2
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(shape, device="cuda") for _ in range(3))
+    ref = oracle.attn_naive(*(oracle.round_f16(x.cpu().numpy()) for x in (q, k, v)))
+    o = pyflash.naive(q, k, v)
+    assert o.dtype == torch.float32 and o.shape == q.shape and o.is_contiguous()
+    assert_close(o.cpu().numpy(), ref, "pyflash.naive fp32 d = 69")
+    assert torch.equal(fa.forward(q, k, v, fa.KernelType.naive1D), o)
+    assert torch.equal(pyflash.mma(q, k, v), o)
