@@ -12,6 +12,7 @@ The directory name contains a hyphen, so import it with
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import enum
 import os
@@ -176,7 +177,9 @@ def forward(Q, K, V, kernel_type=KernelType.mma_qreg_async, *, out=None, sync: b
     elif out.shape != Q.shape or out.dtype != Q.dtype or not out.is_contiguous() or out.device != Q.device:
         raise ValueError("out must be a contiguous tensor like Q")
     scale = 1.0 / float(d) ** 0.5
-    with torch.cuda.device(Q.device):
+    # (entering a device context costs 2-3 us per call, which shows at short sequences: only when needed)
+    ctx = contextlib.nullcontext() if Q.device.index == torch.cuda.current_device() else torch.cuda.device(Q.device)
+    with ctx:
         stream = torch.cuda.current_stream(Q.device)
         sp = ctypes.c_void_p(stream.cuda_stream)
         if Q.dtype in (torch.float16, torch.bfloat16):
